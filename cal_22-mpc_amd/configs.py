@@ -1,0 +1,106 @@
+"""VPC JSON configuration authoring.
+
+The reference ships no sample configuration; its schema is defined only by
+``VPC::parseConfig`` (reference ``src/compressor/VPC.cpp:72-330``).  This module
+writes configurations in exactly that schema:
+
+``overview``: ``num_modules`` (M), ``lineSize`` (L), optional ``encoding_bits``
+(M+1 ints, element k -> cluster k-1, ``VPC.cpp:111-115``).
+``modules``: object keyed ``"0"``..``"M-1"``; ``name`` in ``AllZero`` |
+``AllWordSame``/``ByteplaneAllSame`` | ``PredComp``; ``PredComp.submodules`` =
+``ResidueModule.PredictorModule{name, LineSize, RootIndex, [BaseIndexTable,
+WeightTable | DiffTable]}``, ``XORModule.consecutiveXOR``,
+``ScanModule{TableSize, Rows, Cols}``, ``FPCModule{num_modules, ...}``
+(parsed by the reference, then unused: ``VPC.cpp:303-306``).
+"""
+from __future__ import annotations
+
+import json
+from typing import Dict, List, Optional
+
+
+def plane_major_scan(line_size: int) -> Dict:
+    """Identity plane-major scan: scanned bit i = XORed plane i // L, column i % L
+    (``ScanModule.cpp:13-19``)."""
+    n = 8 * line_size
+    return {
+        "TableSize": n,
+        "Rows": [i // line_size for i in range(n)],
+        "Cols": [i % line_size for i in range(n)],
+    }
+
+
+def _pred_comp(pred: Dict, consecutive_xor: bool, scan: Dict) -> Dict:
+    return {
+        "name": "PredComp",
+        "submodules": {
+            "ResidueModule": {"PredictorModule": pred},
+            "XORModule": {"consecutiveXOR": bool(consecutive_xor)},
+            "ScanModule": scan,
+            "FPCModule": {"num_modules": 0},
+        },
+    }
+
+
+def one_base(line_size: int, root: int = 0, consecutive_xor: bool = True, scan=None) -> Dict:
+    pred = {"name": "OneBasePredictor", "LineSize": line_size, "RootIndex": root}
+    return _pred_comp(pred, consecutive_xor, scan or plane_major_scan(line_size))
+
+
+def consecutive_base(line_size: int, root: int = 0, consecutive_xor: bool = True, scan=None) -> Dict:
+    pred = {"name": "ConsecutiveBasePredictor", "LineSize": line_size, "RootIndex": root}
+    return _pred_comp(pred, consecutive_xor, scan or plane_major_scan(line_size))
+
+
+def diff_base(line_size: int, base: List[int], diff: List[int], root: int = 0,
+              consecutive_xor: bool = False, scan=None) -> Dict:
+    assert len(base) == line_size and len(diff) == line_size
+    pred = {"name": "DiffBasePredictor", "LineSize": line_size, "RootIndex": root,
+            "BaseIndexTable": list(map(int, base)), "DiffTable": list(map(int, diff))}
+    return _pred_comp(pred, consecutive_xor, scan or plane_major_scan(line_size))
+
+
+def weight_base(line_size: int, base: List[int], weight: List[float], root: int = 0,
+                consecutive_xor: bool = True, scan=None) -> Dict:
+    assert len(base) == line_size and len(weight) == line_size
+    pred = {"name": "WeightBasePredictor", "LineSize": line_size, "RootIndex": root,
+            "BaseIndexTable": list(map(int, base)), "WeightTable": list(map(float, weight))}
+    return _pred_comp(pred, consecutive_xor, scan or plane_major_scan(line_size))
+
+
+def make_config(line_size: int, modules: List[Dict], encoding_bits: Optional[List[int]] = None) -> Dict:
+    cfg = {
+        "overview": {"num_modules": len(modules), "lineSize": line_size},
+        "modules": {str(i): m for i, m in enumerate(modules)},
+    }
+    if encoding_bits is not None:
+        assert len(encoding_bits) == len(modules) + 1
+        cfg["overview"]["encoding_bits"] = list(map(int, encoding_bits))
+    return cfg
+
+
+def probe_config(line_size: int = 64, encoding_bits: Optional[List[int]] = None) -> Dict:
+    """The 6-module configuration SURVEY.md 8c quotes known answers for:
+    AllZero, AllWordSame, OneBase(consecutive XOR), ConsecutiveBase(consecutive
+    XOR), DiffBase(base[i]=max(i-4,0), diff 1 on word-LSBs, plane-0 XOR),
+    WeightBase(base[i]=max(i-4,0), weight 1 / 0.5 on even / odd bytes,
+    consecutive XOR); identity plane-major scan; default id bits."""
+    L = line_size
+    base = [max(i - 4, 0) for i in range(L)]
+    diff = [1 if i % 4 == 0 else 0 for i in range(L)]
+    weight = [1.0 if i % 2 == 0 else 0.5 for i in range(L)]
+    mods = [
+        {"name": "AllZero"},
+        {"name": "AllWordSame"},
+        one_base(L, 0, True),
+        consecutive_base(L, 0, True),
+        diff_base(L, base, diff, 0, False),
+        weight_base(L, base, weight, 0, True),
+    ]
+    return make_config(L, mods, encoding_bits)
+
+
+def write_config(cfg: Dict, path: str) -> str:
+    with open(path, "w") as f:
+        json.dump(cfg, f)
+    return path

@@ -1,0 +1,145 @@
+"""Synthetic trace generators (host side, numpy) for the workloads of
+BASELINE.json / SURVEY.md 8d.  Each returns a C-order ``uint8`` array of shape
+``[n_lines, line_size]`` -- the layout ``trace::LoaderNPY`` serves
+(reference ``src/loader/LoaderNPY.cpp:14-54``).
+
+The full-size device-resident versions used by ``bench.py`` are produced by the
+HIP generators behind ``mpc_synth_*`` (``csrc/mpc_synth.hip``), which are checked
+against these functions on a prefix (tests/test_gpu_parity.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED = 12345
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """Counter-based generator: splitmix64 finaliser of (index + seed stream).
+    Pure function of the counter, so any shard can be generated independently."""
+    x = x.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _rand_u32(first_word: int, n_words: int, seed: int = SEED) -> np.ndarray:
+    idx = np.arange(first_word, first_word + n_words, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        key = idx + np.uint64(seed) * np.uint64(0xD1342543DE82EF95)
+    return (splitmix64(key) >> np.uint64(32)).astype(np.uint32)
+
+
+def zeros(n_lines: int, line_size: int = 64) -> np.ndarray:
+    return np.zeros((n_lines, line_size), dtype=np.uint8)
+
+
+def random_u32(n_lines: int, line_size: int = 64, first_line: int = 0, seed: int = SEED) -> np.ndarray:
+    """Config 2: every 32-bit word i.i.d. uniform, little-endian."""
+    wpl = line_size // 4
+    w = _rand_u32(first_line * wpl, n_lines * wpl, seed)
+    return w.astype("<u4").view(np.uint8).reshape(n_lines, line_size)
+
+
+def sine_table() -> np.ndarray:
+    """float32(sin(2*pi*t/1024)) for t in [0,1024): the period of config 3."""
+    t = np.arange(1024, dtype=np.float64)
+    return np.sin(2.0 * np.pi * t / 1024.0).astype(np.float32)
+
+
+def sine_f32(n_lines: int, line_size: int = 64, first_line: int = 0) -> np.ndarray:
+    """Config 3: word t (global index) = float32(sin(2*pi*t/1024))."""
+    wpl = line_size // 4
+    t = np.arange(first_line * wpl, (first_line + n_lines) * wpl, dtype=np.int64)
+    w = sine_table()[t % 1024]
+    return w.astype("<f4").view(np.uint8).reshape(n_lines, line_size)
+
+
+def mixed(n_lines: int, line_size: int = 64, first_line: int = 0) -> np.ndarray:
+    """Config 4: even lines = 16 x uint32((16*line + j) mod 1000); odd lines =
+    the sine words of config 3 at the same global word index."""
+    wpl = line_size // 4
+    lines = np.arange(first_line, first_line + n_lines, dtype=np.int64)
+    j = np.arange(wpl, dtype=np.int64)
+    gidx = lines[:, None] * wpl + j[None, :]
+    ints = ((lines[:, None] * 16 + j[None, :]) % 1000).astype("<u4")
+    sines = sine_table()[gidx % 1024].astype("<f4").view("<u4")
+    w = np.where((lines % 2 == 0)[:, None], ints, sines).astype("<u4")
+    return np.ascontiguousarray(w).view(np.uint8).reshape(n_lines, line_size)
+
+
+def pointers_u64(n_lines: int, line_size: int = 128, first_line: int = 0, seed: int = SEED) -> np.ndarray:
+    """Config 5: qwords 0x00007f3a5c000000 + 8*u, u uniform in [0, 2^20)."""
+    qpl = line_size // 8
+    u = _rand_u32(first_line * qpl, n_lines * qpl, seed).astype(np.uint64) & np.uint64((1 << 20) - 1)
+    q = np.uint64(0x00007F3A5C000000) + np.uint64(8) * u
+    return q.astype("<u8").view(np.uint8).reshape(n_lines, line_size)
+
+
+def word_same(n_lines: int, line_size: int = 64, seed: int = SEED) -> np.ndarray:
+    """Every line repeats one random non-zero 32-bit word."""
+    w = _rand_u32(0, n_lines, seed) | np.uint32(1)
+    return np.repeat(w.astype("<u4"), line_size // 4).view(np.uint8).reshape(n_lines, line_size)
+
+
+def counters_u32(n_lines: int, line_size: int = 32, first_line: int = 0) -> np.ndarray:
+    """Small incrementing 32-bit counters (a compressible integer pattern)."""
+    wpl = line_size // 4
+    idx = np.arange(first_line * wpl, (first_line + n_lines) * wpl, dtype=np.int64)
+    return (idx % 251).astype("<u4").view(np.uint8).reshape(n_lines, line_size)
+
+
+def bdi_stress(n_lines: int, line_size: int = 64, seed: int = 777) -> np.ndarray:
+    """Lines that exercise every BDI mode (reference ``BDI.cpp:6-74``): zeros,
+    8-byte repeats, each (base, delta) combination, deltas of exactly -1
+    (rejected by reduceSign, ``BDI.cpp:203-218``), +128..+255 one-byte deltas
+    (accepted), all-immediate lines (the unsigned wrap of ``BDI.cpp:200``) and
+    random lines."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n_lines, line_size), dtype=np.uint8)
+    for i in range(n_lines):
+        k = i % 14
+        if k == 0:
+            continue
+        if k == 1:
+            q = rng.integers(1, 1 << 63, dtype=np.uint64)
+            out[i] = np.full(line_size // 8, q, dtype="<u8").view(np.uint8)
+            continue
+        if k == 13:
+            out[i] = rng.integers(0, 256, line_size, dtype=np.uint8)
+            continue
+        base_size, delta_size = [(8, 1), (8, 2), (8, 4), (4, 1), (4, 2), (2, 1),
+                                 (8, 1), (4, 1), (2, 1), (8, 2), (4, 2)][k - 2]
+        n = line_size // base_size
+        bits = 8 * base_size
+        base = int(rng.integers(1 << (bits - 2), 1 << (bits - 1), dtype=np.uint64))
+        if k >= 8:
+            variant = (i // 14) % 4
+        else:
+            variant = 0
+        if variant == 0:      # small non-negative deltas
+            d = rng.integers(0, 1 << (8 * delta_size - 1), n)
+        elif variant == 1:    # a delta of exactly -1 somewhere
+            d = rng.integers(0, 4, n)
+            d[rng.integers(1, n)] = -1
+        elif variant == 2:    # +128..+255-style deltas (top bit of the delta set)
+            d = rng.integers(1 << (8 * delta_size - 1), 1 << (8 * delta_size), n)
+        else:                 # all-immediate line (values fit the delta width)
+            base = 0
+            d = rng.integers(0, 1 << (8 * delta_size), n)
+        vals = [(base + int(x)) % (1 << bits) for x in d]
+        if variant != 3 and n > 2:
+            vals[int(rng.integers(1, n))] = int(rng.integers(0, 1 << (8 * delta_size)))  # an immediate
+        arr = np.array(vals, dtype=np.uint64)
+        out[i] = arr.astype({2: "<u2", 4: "<u4", 8: "<u8"}[base_size]).view(np.uint8)
+    return out
+
+
+def save_npy(path: str, lines: np.ndarray) -> str:
+    assert lines.dtype == np.uint8 and lines.ndim == 2
+    np.save(path, np.ascontiguousarray(lines))
+    return path

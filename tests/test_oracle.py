@@ -1,0 +1,214 @@
+"""CPU oracle pinned against (a) the known answers SURVEY.md 8c / BASELINE.md 2
+captured from the reference's object code, (b) vectors produced by the
+reference's own stage classes (tests/golden/ref_stage_vectors.json), and
+(c) that same reference build live, where /root/reference is mounted."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+# ---------------------------------------------------------------- known answers
+def test_kat_vpc_zero_wordsame_random(oracle, configs, traces):
+    v = oracle.VpcOracle(configs.probe_config(64))
+    s, sel = v.compress(traces.zeros(1000))
+    assert (s == 3).all() and (sel == 0).all()
+    assert repr(v.st.comp_ratio) == "170.66666666666666"
+    v.reset()
+    s, sel = v.compress(traces.word_same(1000))
+    assert (s == 35).all() and (sel == 1).all()
+    v.reset()
+    s, sel = v.compress(traces.random_u32(4096))
+    assert (s == 515).all() and (sel == -1).all()
+    assert repr(v.st.comp_ratio) == "0.9941747572815534"
+
+
+def test_kat_vpc_sine(oracle, configs, traces):
+    # 4096-line fp32 sine: 3456 lines at 515 (cluster -1), rest cluster 5,
+    # total 2 105 344 bits
+    v = oracle.VpcOracle(configs.probe_config(64))
+    s, sel = v.compress(traces.sine_f32(4096))
+    assert int((s == 515).sum()) == 3456
+    assert int((sel == -1).sum()) == 3456 and int((sel == 5).sum()) == 640
+    assert int(s.astype(np.int64).sum()) == 2105344
+    assert v.st.compressed_bits == 2105344
+
+
+def test_kat_vpc_128(oracle, configs, traces):
+    v = oracle.VpcOracle(configs.probe_config(128))
+    s, sel = v.compress(traces.random_u32(64, 128))
+    assert (s == 1027).all() and (sel == -1).all()
+
+
+def test_kat_bdi(oracle, traces):
+    b = oracle.BdiOracle(64)
+    assert (b.compress(traces.zeros(8))[0] == 12).all()
+    rep = np.tile(np.arange(1, 9, dtype=np.uint8), (8, 8))
+    s, sel = b.compress(rep)
+    assert (s == 68).all() and (sel == 1).all()
+    s, sel = b.compress(traces.random_u32(2000))
+    assert (s == 516).all() and (sel == 8).all()
+    b128 = oracle.BdiOracle(128)
+    s, sel = b128.compress(traces.pointers_u64(4096))
+    assert (s == 564).all() and (sel == 4).all()  # all B8D4
+
+
+def test_bdi_reduce_sign_quirks(oracle):
+    rs = oracle.lib().mpc_o_bdi_reduce_sign
+    M = (1 << 64) - 1
+    assert rs(5) == 5 and rs(255) == 255
+    assert rs(M) == M                      # -1 is returned unchanged -> never fits
+    assert rs(M - 1) == 2                  # -2 -> 0b10
+    assert rs((-128) & M) == 0x80          # -128 -> 8 low bits
+    assert rs((-129) & M) == 0x17F         # -129 -> 9 low bits
+    assert rs(1 << 63) == (1 << 63)        # i = 62 -> keeps 64 bits
+
+
+def test_bdi_all_immediate_wrap(oracle):
+    # all values immediate: (maskSize - imm - 1) wraps in 32-bit unsigned (BDI.cpp:200)
+    line = np.arange(64, dtype=np.uint8) % 7
+    line[1::2] = 0
+    L = 64
+    got = oracle.lib().mpc_o_bdi_check(line.ctypes.data, L, 2, 1)
+    n = L // 2
+    assert got == (n + 8 * (n * 1 + 2 - 1)) % (1 << 32)
+
+
+# ------------------------------------------------------- golden reference vectors
+def _module(oracle, v):
+    m = oracle.OModule()
+    L = v["L"]
+    m.kind = oracle.KIND_PREDCOMP
+    m.pred_kind = v["kind"]
+    m.root = v["root"]
+    m.consecutive_xor = v["cx"]
+    for j in range(L):
+        m.base[j] = v["base"][j] if v["base"] else 0
+        m.weight[j] = v["weight"][j] if v["weight"] else 1.0
+        m.diff[j] = v["diff"][j] if v["diff"] else 0
+    if v["scan"] is None:
+        rows = [i // L for i in range(8 * L)]
+        cols = [i % L for i in range(8 * L)]
+    else:
+        rows, cols = v["scan"]["rows"], v["scan"]["cols"]
+    m.table_size = len(rows)
+    for j in range(len(rows)):
+        m.rows[j] = rows[j]
+        m.cols[j] = cols[j]
+    return m
+
+
+def test_oracle_matches_golden_stage_vectors(oracle, golden_dir):
+    with open(os.path.join(golden_dir, "ref_stage_vectors.json")) as f:
+        g = json.load(f)
+    lib = oracle.lib()
+    assert len(g["stage_vectors"]) >= 100
+    for v in g["stage_vectors"]:
+        L = v["L"]
+        m = _module(oracle, v)
+        line = np.frombuffer(bytes.fromhex(v["line"]), dtype=np.uint8).copy()
+        pred = np.zeros(L, np.uint8)
+        res = np.zeros(L, np.uint8)
+        sc = np.zeros(8 * L // 16, np.uint16)
+        lib.mpc_o_predict(C.byref(m), L, line.ctypes.data, pred.ctypes.data)
+        lib.mpc_o_residue(C.byref(m), L, line.ctypes.data, res.ctypes.data)
+        lib.mpc_o_scanned(C.byref(m), L, line.ctypes.data, sc.ctypes.data)
+        assert pred.tobytes().hex() == v["pred"]
+        assert res.tobytes().hex() == v["residue"]
+        assert [int(x) for x in sc] == v["scanned"]
+        assert lib.mpc_o_fpc_size(sc.ctypes.data, len(sc)) == v["fpc"]
+        # GetMAE/GetMSE: residues over all positions as unsigned bytes
+        r = (line.astype(np.int64) - pred.astype(np.int64)) % 256
+        assert float(r.sum()) / L == float.fromhex(v["mae"])
+        assert float((r * r).sum()) / L == float.fromhex(v["mse"])
+    for e in g["encoder_vectors"]:
+        rows = np.array(e["rows"], dtype=np.uint16)
+        assert lib.mpc_o_fpc_size(rows.ctypes.data, len(rows)) == e["size"]
+
+
+# ------------------------------------------------------ live reference stage build
+def test_oracle_matches_live_reference_stages(oracle, configs):
+    R = oracle.ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference tree not mounted)")
+    lib = oracle.lib()
+    rng = np.random.default_rng(99)
+    for L in (32, 64, 128):
+        oc = oracle.config_from_json(configs.probe_config(L))
+        for mi in range(2, 6):
+            m = oc.modules[mi]
+            base = np.array(list(m.base)[:L], dtype=np.int32)
+            weight = np.array(list(m.weight)[:L], dtype=np.float32)
+            if m.pred_kind != 0:
+                weight[:] = 1.0
+            diff = np.array(list(m.diff)[:L], dtype=np.int32)
+            rows = np.array(list(m.rows)[: m.table_size], dtype=np.int32)
+            cols = np.array(list(m.cols)[: m.table_size], dtype=np.int32)
+            for trial in range(300):
+                kind = trial % 4
+                if kind == 0:
+                    line = rng.integers(0, 256, L, dtype=np.uint8)
+                elif kind == 1:
+                    line = np.zeros(L, np.uint8)
+                    line[rng.integers(0, L, 3)] = rng.integers(0, 256, 3)
+                elif kind == 2:
+                    w = (rng.integers(0, 1000) + np.arange(L // 4) * rng.integers(0, 5)).astype("<u4")
+                    line = w.view(np.uint8).copy()
+                else:
+                    t = rng.integers(0, 1 << 20) + np.arange(L // 4)
+                    line = np.sin(2 * np.pi * t / 1024).astype("<f4").view(np.uint8).copy()
+                ref_sc = np.zeros(8 * L // 16, np.uint16)
+                my_sc = np.zeros(8 * L // 16, np.uint16)
+                R.ref_scanned(m.pred_kind, m.root, L, base.ctypes.data, weight.ctypes.data,
+                              diff.ctypes.data, m.consecutive_xor, m.table_size, rows.ctypes.data,
+                              cols.ctypes.data, line.ctypes.data, ref_sc.ctypes.data)
+                lib.mpc_o_scanned(C.byref(m), L, line.ctypes.data, my_sc.ctypes.data)
+                assert (ref_sc == my_sc).all()
+                assert R.ref_fpc_size(ref_sc.ctypes.data, len(ref_sc)) == \
+                    lib.mpc_o_fpc_size(my_sc.ctypes.data, len(my_sc))
+
+
+# ------------------------------------------------------------ statistics plumbing
+def test_stats_consistency(oracle, configs, traces):
+    v = oracle.VpcOracle(configs.probe_config(64))
+    lines = np.concatenate([traces.zeros(10), traces.word_same(7), traces.mixed(500),
+                            traces.random_u32(100)])
+    s, sel = v.compress(lines)
+    st = v.st
+    assert st.lines == len(lines)
+    assert st.original_bits == 512 * len(lines)
+    assert st.compressed_bits == int(s.astype(np.int64).sum())
+    h = v.hist()
+    for c in range(-1, 6):
+        k = c + 1
+        assert st.count[k] == int((sel == c).sum())
+        assert int(h[k].sum()) == st.count[k]
+        # MAE/MSE only for lines that reached checkOtherPatterns (VPC.cpp:412)
+        expect = 0 if c in (0, 1) else st.count[k]
+        assert st.residue_lines[k] == expect
+        if expect:
+            # integer sums reproduce the reference's running doubles (L power of 2)
+            assert st.sum_mae[k] == st.sum_r[k] / 64.0
+            assert st.sum_mse[k] == st.sum_r2[k] / 64.0
+    vec = v.stats_vector()
+    assert vec[0] == len(lines) and len(vec) == 3 + 7 * 6 + 7 * v.bins
+
+
+def test_rejects_ub_configs(oracle, configs):
+    cfg = configs.probe_config(64)
+    cfg["modules"]["0"], cfg["modules"]["2"] = cfg["modules"]["2"], cfg["modules"]["0"]
+    with pytest.raises(ValueError):
+        oracle.VpcOracle(cfg)
+    cfg = configs.make_config(64, [{"name": "AllZero"}, configs.consecutive_base(64, root=3)])
+    with pytest.raises(ValueError):
+        oracle.VpcOracle(cfg)
+
+
+def test_only_allzero_config(oracle, configs, traces):
+    # no prediction module: empty scanned array -> size 0 + id bits, cluster -1
+    cfg = configs.make_config(64, [{"name": "AllZero"}])
+    v = oracle.VpcOracle(cfg)
+    s, sel = v.compress(traces.random_u32(4))
+    assert (s == 1).all() and (sel == -1).all()
