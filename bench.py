@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement: 64 B blocks/s through the VPC evaluator on
+device-resident synthetic traces, with the kernel's achieved fraction of the
+MI355X HBM read roofline and a timed CPU baseline beside it.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the evaluator over this rank's shard of the trace (one
+kernel launch over `--lines` blocks already resident in HBM) followed, for N>1,
+by the one real exchange of the path: a sum all-reduce (RCCL) of the integer
+statistics vector.  Lines shard contiguously over ranks (weak scaling: the
+per-GPU shard is fixed, config.workload names it); there is no other collective.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "cal_22-mpc_amd"
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (synth kind, line size, config builder line size)
+    "random_u32": ("random_u32", 64),
+    "sine_f32": ("sine_f32", 64),
+    "mixed": ("mixed", 64),
+    "zeros": ("zeros", 64),
+    "pointers_u64_128": ("pointers_u64", 128),
+}
+
+
+def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0):
+    """The oracle (a CPU port of the reference algorithm, NOT the product path) timed on
+    this host's cores over a bounded sample of the same workload."""
+    from oracle import oracle as O
+    kind = WORKLOADS[workload][0]
+    gen = {"random_u32": traces.random_u32, "sine_f32": traces.sine_f32, "mixed": traces.mixed,
+           "zeros": traces.zeros, "pointers_u64": traces.pointers_u64}[kind]
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    cfg = configs.probe_config(L)
+    # calibrate on a short run, then size the sample for ~`seconds` of wall time
+    cal_n = 4096
+    cal = gen(cal_n, L)
+    o = O.VpcOracle(cfg)
+    t0 = time.perf_counter()
+    o.compress(cal, stats=True)
+    rate1 = cal_n / (time.perf_counter() - t0)
+    per_thread = int(min(max(rate1 * seconds, 4096), 4 << 20))
+    data = gen(per_thread, L)
+    oracles = [O.VpcOracle(cfg) for _ in range(cores)]
+    ths = [threading.Thread(target=oracles[i].compress, args=(data,)) for i in range(cores)]  # ctypes drops the GIL
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": cores * per_thread / dt, "unit": "blocks/s", "cores": cores, "kind": "port",
+            "sample": f"{per_thread} {workload} {L} B blocks per thread x {cores} threads "
+                      f"(oracle/mpc_oracle.c, probe config), {dt:.1f} s",
+            "single_core_blocks_per_s": rate1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="random_u32", choices=sorted(WORKLOADS))
+    ap.add_argument("--lines", type=int, default=256 << 20, help="blocks per GPU (default 256 Mi = 16 GiB at 64 B)")
+    ap.add_argument("--algo", default="VPC", choices=["VPC", "BDI"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), copied into roofline.traffic")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    mpc = importlib.import_module(PKG)
+    configs = importlib.import_module(f"{PKG}.configs")
+    traces = importlib.import_module(f"{PKG}.traces")
+
+    kind, L = WORKLOADS[args.workload]
+    n = args.lines
+    buf = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    mpc.synth_fill(buf.data_ptr(), n, L, kind, first_line=rank * n)
+    torch.cuda.synchronize()
+    if args.algo == "VPC":
+        ev = mpc.VPC(configs.probe_config(L), device=local_rank)
+    else:
+        ev = mpc.BDI(L, device=local_rank)
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
+
+    def step(ev_pair=None):
+        if ev_pair is not None:
+            ev_pair[0].record(stream)
+        ev.compress_device(buf.data_ptr(), n, stream=sp)
+        if ev_pair is not None:
+            ev_pair[1].record(stream)
+        if world > 1:
+            # the path's only exchange: sum all-reduce of the integer statistics vector
+            v = torch.from_numpy(ev.stats_vector().view(np.int64)).to(dev)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            return v
+        return None
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev.reset()
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(pairs[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    kern_ms = [a.elapsed_time(b) for a, b in pairs]
+    avg_kern_s = (sum(kern_ms) / len(kern_ms)) / 1e3
+    # sanity: every block of every step was counted exactly once
+    v = ev.stats_vector()
+    assert int(v[0]) == n * args.steps, (int(v[0]), n * args.steps)
+    ratio = float(v[1]) / float(v[2])
+
+    # measured streaming-read ceiling on the same buffer
+    probe_ms = []
+    for _ in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        mpc.read_bandwidth_probe(buf.data_ptr(), n * L, stream=sp)
+        b.record(stream)
+        torch.cuda.synchronize()
+        probe_ms.append(a.elapsed_time(b))
+    probe_gbps = n * L / (min(probe_ms[1:]) / 1e3) / 1e9
+
+    if rank == 0:
+        achieved = n * L / avg_kern_s / 1e9     # algorithmic bytes: L read per block
+        out = {
+            "metric": "64B blocks/s (whole node) + achieved HBM GB/s fraction; ratio bit-exact vs CPU",
+            "value": world * n * args.steps / dt,
+            "unit": "blocks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"{n} {args.workload} {L} B blocks per GPU, {args.algo}"
+                                   + (" probe config (6 modules, all predictors)" if args.algo == "VPC" else ""),
+                       "algorithm": args.algo, "line_size": L, "blocks_per_gpu": n,
+                       "sharding": f"contiguous x{world}", "compression_ratio": ratio},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": args.traffic_bytes,
+                         "kernel": "vpc_fast_kernel<4>" if (args.algo == "VPC" and L == 64) else args.algo,
+                         "kernel_ms_avg": avg_kern_s * 1e3, "kernel_ms_min": min(kern_ms),
+                         "algorithmic_bytes_per_launch": n * L,
+                         "read_probe_gbps": probe_gbps, "frac_of_read_probe": achieved / probe_gbps},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(configs, traces, args.workload, L)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

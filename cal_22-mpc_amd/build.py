@@ -1,0 +1,75 @@
+"""In-tree build of the native code (gfx950 only).
+
+    python "cal_22-mpc_amd/build.py"          # libmpc_hip.so + bin/compressor
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+LIB = os.path.join(HERE, "libmpc_hip.so")
+CLI = os.path.join(ROOT, "bin", "compressor")
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _sources(d: str):
+    out = []
+    for dirpath, _, files in os.walk(d):
+        for f in files:
+            if f.endswith((".hip", ".h", ".cpp", ".hpp")):
+                out.append(os.path.join(dirpath, f))
+    return out
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    deps = _sources(CSRC) + [os.path.join(ROOT, "include", "mpc_hip.h")]
+    if not force and _newer(LIB, deps):
+        return LIB
+    cmd = [HIPCC, *FLAGS, "-shared", "-o", LIB,
+           os.path.join(CSRC, "mpc_kernels.hip"), os.path.join(CSRC, "mpc_capi.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> str:
+    """bin/compressor: the reference's CLI (src/main.cpp) over libmpc_hip.so."""
+    if not os.path.isdir(HOST):
+        return ""
+    deps = _sources(HOST) + [LIB]
+    if not force and _newer(CLI, deps):
+        return CLI
+    srcs = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith(".cpp")]
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", CLI, *srcs,
+           "-L", HERE, "-lmpc_hip", "-Wl,-rpath,$ORIGIN/../cal_22-mpc_amd"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return CLI
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_lib(force, verbose)
+    build_cli(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

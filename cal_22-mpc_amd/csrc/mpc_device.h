@@ -1,0 +1,61 @@
+// mpc_device.h -- parameter blocks shared by the host side (mpc_capi.hip) and the
+// gfx950 kernels (mpc_kernels.hip).  Plain C structs, passed by value as kernel
+// arguments.
+#pragma once
+
+#include <stdint.h>
+
+#define MPC_MAX_MODULES 16        /* M (AllZero + AllWordSame + prediction modules) */
+#define MPC_MAX_PRED    15        /* prediction (PredComp) modules */
+#define MPC_MAX_LINE    256       /* bytes per line, generic path */
+
+/* fast-path predictor forms (see DESIGN.md "Fast path") */
+enum {
+  MPC_FK_ONEBASE = 0,  /* every byte predicted by byte 0                         */
+  MPC_FK_CONSEC  = 1,  /* previous byte of the byte-plane-shuffled line          */
+  MPC_FK_DIFF    = 2,  /* base byte in own/previous dword (v_perm) + constant     */
+  MPC_FK_WEIGHT  = 3   /* base byte in own/previous dword (v_perm), <=2 shifts    */
+};
+
+struct MpcFastModule {
+  int32_t kind;       /* MPC_FK_* */
+  int32_t cx;         /* consecutiveXOR */
+  int32_t ls1, rs1;   /* WEIGHT: first shift class  ((b << ls1) >> rs1) & c1 */
+  int32_t ls2, rs2;   /* WEIGHT: second shift class ((b << ls2) >> rs2) & c2 */
+  int32_t tab_off;    /* DIFF/WEIGHT: dword offset of {sel[L/4], c1[L/4], c2[L/4]} in tab */
+  int32_t pad;
+};
+
+/* generic-path module tables: byte offsets into MpcVpcParams::gtab */
+struct MpcGenModule {
+  int32_t pred_kind;  /* 0 weight, 1 diff, 2 onebase, 3 consecutive */
+  int32_t root;
+  int32_t cx;
+  int32_t table_size;
+  int32_t off_base;   /* uint8 [L]  BaseIndexTable                  */
+  int32_t off_shift;  /* int8  [L]  weight shift distance (clamped) */
+  int32_t off_diff;   /* uint8 [L]  (uint8_t)DiffTable              */
+  int32_t off_rows;   /* uint8 [table_size]                         */
+  int32_t off_cols;   /* uint8 [table_size]                         */
+  int32_t pad[3];
+};
+
+struct MpcVpcParams {
+  int32_t L;            /* line size in bytes */
+  int32_t M;            /* num_modules */
+  int32_t n_pred;       /* number of PredComp modules */
+  int32_t start;        /* module index of the first PredComp module (1 or 2) */
+  int32_t has_aws;      /* module 1 is AllWordSame */
+  int32_t hist_bins;    /* bins per cluster */
+  int32_t enc_bits[MPC_MAX_MODULES + 1];  /* index cluster+1 */
+  struct MpcFastModule fm[MPC_MAX_PRED];
+  struct MpcGenModule gm[MPC_MAX_PRED];
+  const uint32_t *tab;  /* fast path dword tables (device) */
+  const uint8_t *gtab;  /* generic path byte tables (device) */
+};
+
+/* Device-side raw statistics (uint64 each):
+ *   VPC: [0,K) sum_r   [K,2K) sum_r2   [2K, 2K + K*bins) histogram[k][size]
+ *   BDI: [0,9) Counts  [9] compressed_bits                                   */
+static inline uint64_t mpc_vpc_raw_len(int K, int bins) { return 2ull * (uint64_t)K + (uint64_t)K * (uint64_t)bins; }
+#define MPC_BDI_RAW_LEN 10

@@ -143,3 +143,51 @@ def save_npy(path: str, lines: np.ndarray) -> str:
     assert lines.dtype == np.uint8 and lines.ndim == 2
     np.save(path, np.ascontiguousarray(lines))
     return path
+
+
+def structured(n_lines: int, line_size: int = 64, seed: int = 4242) -> np.ndarray:
+    """A mix of compressible patterns that drives every branch of the selector and
+    of the common encoder (zero runs, single ones, adjacent pairs, half rows)."""
+    rng = np.random.default_rng(seed)
+    L, W = line_size, line_size // 4
+    out = np.zeros((n_lines, L), dtype=np.uint8)
+    for i in range(n_lines):
+        k = i % 12
+        if k == 0:      # sparse bytes
+            m = int(rng.integers(1, 6))
+            out[i, rng.integers(0, L, m)] = rng.integers(1, 256, m)
+        elif k == 1:    # repeated word + low-bit noise
+            w = rng.integers(0, 1 << 32, dtype=np.uint64).astype(np.uint32)
+            noise = rng.integers(0, 1 << int(rng.integers(1, 9)), W).astype(np.uint32)
+            out[i] = (w + noise).astype("<u4").view(np.uint8)
+        elif k == 2:    # counters with a random stride
+            s0, st = int(rng.integers(0, 1 << 30)), int(rng.integers(0, 300))
+            out[i] = (s0 + st * np.arange(W)).astype("<u4").view(np.uint8)
+        elif k == 3:    # fp32 ramp
+            a, b = rng.normal(), rng.normal() * 1e-3
+            out[i] = (a + b * np.arange(W)).astype("<f4").view(np.uint8)
+        elif k == 4:    # sine, random phase
+            t = int(rng.integers(0, 1 << 20)) + np.arange(W)
+            out[i] = np.sin(2 * np.pi * t / 1024).astype("<f4").view(np.uint8)
+        elif k == 5:    # byte ramp
+            out[i] = (int(rng.integers(0, 256)) + int(rng.integers(0, 4)) * np.arange(L)).astype(np.uint8)
+        elif k == 6:    # one byte value everywhere but a few positions
+            out[i] = int(rng.integers(1, 256))
+            m = int(rng.integers(0, 4))
+            out[i, rng.integers(0, L, m)] = rng.integers(0, 256, m)
+        elif k == 7:    # single bit set somewhere
+            out[i, int(rng.integers(0, L))] = 1 << int(rng.integers(0, 8))
+        elif k == 8:    # two adjacent bytes with the same single bit
+            p = int(rng.integers(0, L - 1))
+            b = 1 << int(rng.integers(0, 8))
+            out[i, p] = b
+            out[i, p + 1] = b
+        elif k == 9:    # 16-bit values
+            out[i] = rng.integers(0, 1 << int(rng.integers(1, 17)), L // 2).astype("<u2").view(np.uint8)
+        elif k == 10:   # pointer-like qwords
+            u = rng.integers(0, 1 << 16, L // 8).astype(np.uint64)
+            out[i] = (np.uint64(0x00007F3A5C000000) + np.uint64(8) * u).astype("<u8").view(np.uint8)
+        else:           # random with zeroed upper bytes
+            w = rng.integers(0, 1 << int(rng.integers(1, 33)), W, dtype=np.uint64).astype("<u4")
+            out[i] = w.view(np.uint8)
+    return out

@@ -1,0 +1,115 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/mpc_hip.h declares; the native configuration
+parser agrees with the oracle's reading of the same JSON; errors are reported as
+codes, not exits.  No kernel runs here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pkg
+
+
+@pytest.fixture(scope="module")
+def mpc():
+    pkg("build").build_lib()
+    return pkg()
+
+
+def test_header_symbols_exported(mpc):
+    with open(os.path.join(ROOT, "include", "mpc_hip.h")) as f:
+        hdr = f.read()
+    declared = set(re.findall(r"\b(mpc_[a-z_]+)\s*\(", hdr))
+    declared.discard("mpc_handle")
+    assert declared, "no declarations found"
+    lib = C.CDLL(mpc.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in mpc_hip.h but not exported"
+    assert declared == set(mpc.EXPORTED_SYMBOLS)
+
+
+def test_config_describe_matches_oracle_parse(mpc, configs, oracle):
+    for L in (32, 64, 128):
+        cfg = configs.probe_config(L)
+        d = mpc.describe_config(cfg)
+        assert d["rc"] == 0 and d["path"] == "fast", d
+        oc = oracle.config_from_json(cfg)
+        assert d["L"] == oc.line_size and d["M"] == oc.num_modules
+        assert d["enc_bits"] == [oc.enc_bits[k] for k in range(oc.num_modules + 1)]
+        assert d["hist_bins"] == oracle.hist_bins(oc)
+        for i, m in enumerate(d["modules"]):
+            om = oc.modules[i]
+            assert m["kind"] == om.kind
+            if om.kind == 2:
+                assert (m["pred_kind"], m["root"], m["cx"], m["table_size"]) == \
+                    (om.pred_kind, om.root, om.consecutive_xor, om.table_size)
+        # weight 1.0 -> shift 0, weight 0.5 -> shift -1
+        assert d["modules"][5]["shifts"][1:4] == [-1, 0, -1]
+
+
+def test_custom_encoding_bits_and_generic_classification(mpc, configs):
+    cfg = configs.probe_config(64, encoding_bits=[2, 1, 3, 4, 4, 5, 5])
+    d = mpc.describe_config(cfg)
+    assert d["enc_bits"] == [2, 1, 3, 4, 4, 5, 5] and d["hist_bins"] == 512 + 5 + 1
+    # non-zero root -> generic kernel
+    cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, root=7)])
+    d = mpc.describe_config(cfg)
+    assert d["rc"] == 0 and d["path"] == "generic" and "RootIndex" in d["why_generic"]
+    # permuted scan table -> generic kernel
+    scan = configs.plane_major_scan(64)
+    scan["Rows"][0], scan["Rows"][100] = scan["Rows"][100], scan["Rows"][0]
+    cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, scan=scan)])
+    assert mpc.describe_config(cfg)["path"] == "generic"
+    # base table outside the own/previous dword -> generic kernel
+    base = [0] * 64
+    cfg = configs.make_config(64, [{"name": "AllZero"}, configs.diff_base(64, base, [0] * 64)])
+    assert mpc.describe_config(cfg)["path"] == "generic"
+
+
+def test_invalid_configs_are_error_codes(mpc, configs):
+    assert mpc.describe_config("{ not json")["rc"] == -74
+    cfg = configs.probe_config(64)
+    cfg["modules"]["3"]["name"] = "Bogus"
+    d = mpc.describe_config(cfg)
+    assert d["rc"] == -22 and "not a valid compression module" in d["error"]
+    cfg = configs.probe_config(64)
+    cfg["modules"]["0"], cfg["modules"]["2"] = cfg["modules"]["2"], cfg["modules"]["0"]
+    assert mpc.describe_config(cfg)["rc"] == -22          # module 0 must be AllZero
+    cfg = configs.make_config(64, [{"name": "AllZero"}, configs.consecutive_base(64, root=2)])
+    assert mpc.describe_config(cfg)["rc"] == -22          # inputLine[-1] in the reference
+    cfg = configs.probe_config(64)
+    cfg["modules"]["2"]["submodules"]["ResidueModule"]["PredictorModule"]["LineSize"] = 32
+    assert mpc.describe_config(cfg)["rc"] == -22
+
+
+def test_json_reader_jsoncpp_conversions(mpc, configs):
+    # reals truncate to int, ints convert to bool, comments are accepted
+    cfg = configs.probe_config(32)
+    text = json.dumps(cfg).replace('"lineSize": 32', '"lineSize": 32.0 /* c */')
+    text = text.replace('"consecutiveXOR": true', '"consecutiveXOR": 1')
+    d = mpc.describe_config("// leading comment\n" + text)
+    assert d["rc"] == 0 and d["L"] == 32 and d["modules"][2]["cx"] == 1
+
+
+def test_create_without_device_fails_loudly(mpc, configs):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(mpc.MpcError) as e:
+        mpc.VPC(configs.probe_config(64))
+    assert e.value.code == -19 and "no CPU fallback" in str(e.value)
+    with pytest.raises(mpc.MpcError):
+        mpc.BDI(64)
+
+
+def test_npy_shape_probe(mpc, traces, tmp_path):
+    p = str(tmp_path / "t.npy")
+    traces.save_npy(p, traces.random_u32(37, 64))
+    r, c = C.c_uint64(), C.c_uint64()
+    assert mpc.lib().mpc_npy_shape(p.encode(), C.byref(r), C.byref(c)) == 0
+    assert (r.value, c.value) == (37, 64)
+    np.save(str(tmp_path / "f.npy"), np.zeros((4, 64), dtype=np.float32))
+    assert mpc.lib().mpc_npy_shape(str(tmp_path / "f.npy").encode(), C.byref(r), C.byref(c)) == -22

@@ -1,0 +1,287 @@
+"""GPU parity: the HIP path (through the C ABI of include/mpc_hip.h) against the
+CPU oracle on the same inputs -- bit-exact per-line sizes, selected clusters and
+the full integer statistics vector.  Runs on the MI355X box (`-m gpu`)."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mpc():
+    pkg("build").build_lib()
+    return pkg()
+
+
+def _check_vpc(mpc, oracle, cfg, lines, expect_path=None):
+    ev = mpc.VPC(cfg)
+    if expect_path is not None:
+        assert ev.kernel_path == expect_path
+    o = oracle.VpcOracle(cfg)
+    s_ref, sel_ref = o.compress(lines)
+    s, sel = ev.compress_lines(lines)
+    bad = np.nonzero((s != s_ref) | (sel != sel_ref))[0]
+    assert bad.size == 0, (f"{bad.size} mismatching lines, first {bad[:5]}: size {s[bad[:5]]} vs {s_ref[bad[:5]]}, "
+                           f"sel {sel[bad[:5]]} vs {sel_ref[bad[:5]]}")
+    v, v_ref = ev.stats_vector(), o.stats_vector()
+    assert v.shape == v_ref.shape
+    assert (v == v_ref).all(), f"stats differ at {np.nonzero(v != v_ref)[0][:10]}"
+    # derived doubles equal the reference's running doubles (L is a power of two)
+    res = ev.result()
+    assert res["comp_ratio"] == o.st.comp_ratio
+    if ev.line_size & (ev.line_size - 1) == 0:
+        for c in range(-1, ev.num_modules):
+            assert res["clusters"][c]["mae"] == o.st.mae[c + 1]
+            assert res["clusters"][c]["mse"] == o.st.mse[c + 1]
+    ev.close()
+    return s, sel
+
+
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_vpc_fast_path_probe_config(mpc, oracle, configs, traces, L):
+    cfg = configs.probe_config(L)
+    lines = np.concatenate([
+        traces.zeros(70, L), traces.word_same(70, L), traces.random_u32(2000, L),
+        traces.sine_f32(2048, L), traces.mixed(2000, L), traces.counters_u32(1000, L),
+        traces.structured(6000, L), traces.pointers_u64(500, L) if L >= 8 else traces.zeros(1, L),
+        traces.bdi_stress(1400, L),
+    ])
+    rng = np.random.default_rng(5)
+    lines = lines[rng.permutation(len(lines))]
+    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+
+
+def test_vpc_known_answers_on_gpu(mpc, configs, traces):
+    # SURVEY.md 8c known answers, straight from the HIP path
+    ev = mpc.VPC(configs.probe_config(64))
+    s, sel = ev.compress_lines(traces.zeros(1000))
+    assert (s == 3).all() and (sel == 0).all()
+    assert repr(ev.result()["comp_ratio"]) == "170.66666666666666"
+    ev.reset()
+    s, sel = ev.compress_lines(traces.word_same(1000))
+    assert (s == 35).all() and (sel == 1).all()
+    ev.reset()
+    s, sel = ev.compress_lines(traces.random_u32(4096))
+    assert (s == 515).all() and (sel == -1).all()
+    assert repr(ev.result()["comp_ratio"]) == "0.9941747572815534"
+    ev.reset()
+    s, sel = ev.compress_lines(traces.sine_f32(4096))
+    assert int((s == 515).sum()) == 3456 and int((sel == 5).sum()) == 640
+    assert ev.result()["compressed_bits"] == 2105344
+
+
+def test_vpc_fast_path_variants(mpc, oracle, configs, traces):
+    L = 64
+    lines = np.concatenate([traces.structured(4000, L, seed=9), traces.mixed(1000, L), traces.random_u32(500, L)])
+    # custom id bits, no AllWordSame, non-consecutive XOR on every module
+    cfg = configs.make_config(L, [{"name": "AllZero"},
+                                  configs.one_base(L, 0, False),
+                                  configs.consecutive_base(L, 0, False)],
+                              encoding_bits=[1, 2, 5, 7])
+    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+    # windowed tables: previous byte / previous half-word / in-word bases, diffs incl. negatives
+    base1 = [max(i - 1, 0) for i in range(L)]
+    base2 = [max(i - 2, 0) for i in range(L)]
+    base_inword = [4 * (i // 4) if i >= 4 else 0 for i in range(L)]
+    diff = [(-3 + (i % 7)) for i in range(L)]
+    w3 = [[1.0, 0.5, 1.0, 1.0][i % 4] for i in range(L)]
+    w_up = [[2.0, 1.0][i % 2] for i in range(L)]
+    w_big = [[256.0, 0.001][i % 2] for i in range(L)]     # shifts >= 8 / <= -8 clear the byte
+    cfg = configs.make_config(L, [{"name": "AllZero"}, {"name": "ByteplaneAllSame"},
+                                  configs.diff_base(L, base1, diff, 0, True),
+                                  configs.diff_base(L, base2, [0] * L, 0, False),
+                                  configs.weight_base(L, base_inword, w3, 0, True),
+                                  configs.weight_base(L, base1, w_up, 0, False),
+                                  configs.weight_base(L, base2, w_big, 0, True)])
+    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+    # a single prediction module, and none at all
+    cfg = configs.make_config(L, [{"name": "AllZero"}, {"name": "AllWordSame"}, configs.consecutive_base(L)])
+    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+    cfg = configs.make_config(L, [{"name": "AllZero"}])
+    _check_vpc(mpc, oracle, cfg, lines)
+
+
+@pytest.mark.parametrize("L", [32, 64, 128, 48])
+def test_vpc_generic_path(mpc, oracle, configs, traces, L):
+    rng = np.random.default_rng(L)
+    n = 8 * L
+    perm = rng.permutation(n)
+    scan = {"TableSize": n - 16, "Rows": [int(p) // L for p in perm[: n - 16]], "Cols": [int(p) % L for p in perm[: n - 16]]}
+    rb = [int(x) for x in rng.integers(0, L, L)]
+    rd = [int(x) for x in rng.integers(-300, 300, L)]
+    rw = [float(2.0 ** int(x)) for x in rng.integers(-9, 10, L)]
+    mods = [{"name": "AllZero"}, {"name": "AllWordSame"},
+            configs.one_base(L, root=5, consecutive_xor=True),
+            configs.consecutive_base(L, 0, False, scan=scan),
+            configs.diff_base(L, rb, rd, root=3, consecutive_xor=True),
+            configs.weight_base(L, rb, rw, root=L - 1, consecutive_xor=False, scan=scan)]
+    cfg = configs.make_config(L, mods)
+    if L == 48:
+        lines = rng.integers(0, 256, (1500, L), dtype=np.uint8)
+        lines[::3] //= 64
+        lines[::5] = 0
+    else:
+        lines = np.concatenate([traces.structured(2400, L, seed=3), traces.random_u32(300, L),
+                                traces.zeros(20, L), traces.word_same(20, L), traces.mixed(400, L)])
+    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_GENERIC)
+
+
+def test_generic_and_fast_agree(mpc, configs, traces):
+    # the same semantics through both kernels: OneBase(root 0) spelled as a
+    # DiffBase with base 0 / diff 0 everywhere is not "windowed", so that
+    # configuration takes the generic kernel and must give identical results
+    L = 64
+    lines = np.concatenate([traces.structured(3000, L, seed=11), traces.sine_f32(1000, L)])
+    cfg = configs.probe_config(L)
+    fast = mpc.VPC(cfg)
+    assert fast.kernel_path == mpc.MPC_PATH_VPC_FAST
+    s1, c1 = fast.compress_lines(lines)
+    eq = configs.make_config(L, [{"name": "AllZero"}, {"name": "AllWordSame"},
+                                 configs.diff_base(L, [0] * L, [0] * L, 0, True),
+                                 cfg["modules"]["3"], cfg["modules"]["4"], cfg["modules"]["5"]])
+    gen = mpc.VPC(eq)
+    assert gen.kernel_path == mpc.MPC_PATH_VPC_GENERIC
+    s2, c2 = gen.compress_lines(lines)
+    assert (s1 == s2).all() and (c1 == c2).all()
+    assert (fast.stats_vector() == gen.stats_vector()).all()
+
+
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_bdi(mpc, oracle, traces, L):
+    lines = np.concatenate([traces.bdi_stress(5600, L), traces.random_u32(500, L), traces.zeros(30, L),
+                            traces.structured(2400, L), traces.pointers_u64(1000, L), traces.mixed(1000, L)])
+    ev = mpc.BDI(L)
+    o = oracle.BdiOracle(L)
+    s_ref, sel_ref = o.compress(lines)
+    s, sel = ev.compress_lines(lines)
+    bad = np.nonzero((s != s_ref) | (sel != sel_ref))[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}: {s[bad[:5]]} vs {s_ref[bad[:5]]}"
+    assert (ev.stats_vector() == o.stats_vector()).all()
+    assert len(np.unique(sel_ref)) == 9
+    if L == 128:
+        ev.reset()
+        s, sel = ev.compress_lines(traces.pointers_u64(4096, 128))
+        assert (s == 564).all() and (sel == 4).all()
+
+
+def test_edge_cases(mpc, oracle, configs, traces):
+    cfg = configs.probe_config(64)
+    ev = mpc.VPC(cfg)
+    # empty batch
+    s, sel = ev.compress_lines(np.zeros((0, 64), dtype=np.uint8))
+    assert len(s) == 0 and ev.stats_vector()[0] == 0
+    # ragged tails: sizes that do not fill a wave / a workgroup
+    o = oracle.VpcOracle(cfg)
+    for n in (1, 3, 15, 17, 63, 65, 255, 257, 1000):
+        ev.reset(); o.reset()
+        lines = traces.structured(n, 64, seed=n)
+        s, sel = ev.compress_lines(lines)
+        sr, cr = o.compress(lines)
+        assert (s == sr).all() and (sel == cr).all()
+        assert (ev.stats_vector() == o.stats_vector()).all()
+    # statistics accumulate across calls, merge and set behave like integer sums
+    ev.reset(); o.reset()
+    a, b = traces.mixed(777, 64), traces.structured(555, 64)
+    ev.compress_lines(a, want_sizes=False, want_selected=False)
+    ev.compress_lines(b, want_sizes=True, want_selected=False)
+    o.compress(a); o.compress(b)
+    v = ev.stats_vector()
+    assert (v == o.stats_vector()).all()
+    ev.stats_merge(v)
+    assert (ev.stats_vector() == 2 * v).all()
+    ev.stats_set(v)
+    assert (ev.stats_vector() == v).all()
+    # wrong line size is an error code, not a crash
+    with pytest.raises(ValueError):
+        ev.compress_lines(np.zeros((4, 32), dtype=np.uint8))
+
+
+def test_stager_multi_chunk_and_npy(mpc, oracle, configs, traces, tmp_path):
+    # more than two 64 MiB staging chunks, plus the .npy streaming path with the
+    # reference's dropped last row (LoaderNPY.cpp:28-32 + main.cpp:240)
+    cfg = configs.probe_config(64)
+    ev = mpc.VPC(cfg)
+    n = (150 << 20) // 64 + 12345
+    lines = traces.mixed(n, 64)
+    lines[::7] = traces.random_u32((n + 6) // 7, 64)
+    s, sel = ev.compress_lines(lines)
+    o = oracle.VpcOracle(cfg)
+    idx = np.concatenate([np.arange(0, 5000), np.arange(n // 2, n // 2 + 5000), np.arange(n - 5000, n)])
+    sr, cr = o.compress(lines[idx])
+    assert (s[idx] == sr).all() and (sel[idx] == cr).all()
+    v = ev.stats_vector()
+    assert v[0] == n and v[2] == int(s.astype(np.int64).sum())
+    p = str(tmp_path / "trace.npy")
+    traces.save_npy(p, lines[:200001])
+    ev.reset()
+    assert ev.compress_npy(p) == 200000
+    o.reset(); o.compress(lines[:200000])
+    assert (ev.stats_vector() == o.stats_vector()).all()
+    ev.reset()
+    assert ev.compress_npy(p, first_row=1000, n_rows=5000, skip_last_row=False) == 5000
+    o.reset(); o.compress(lines[1000:6000])
+    assert (ev.stats_vector() == o.stats_vector()).all()
+
+
+def test_device_resident_path_and_synth(mpc, oracle, configs, traces):
+    import torch
+    dev = torch.device("cuda:0")
+    for kind, gen, L in (("random_u32", traces.random_u32, 64), ("sine_f32", traces.sine_f32, 64),
+                         ("mixed", traces.mixed, 64), ("pointers_u64", traces.pointers_u64, 128),
+                         ("zeros", traces.zeros, 32)):
+        n, first = 40000, 123457
+        buf = torch.empty(n * L, dtype=torch.uint8, device=dev)
+        mpc.synth_fill(buf.data_ptr(), n, L, kind, first_line=first)
+        torch.cuda.synchronize()
+        host = buf.cpu().numpy().reshape(n, L)
+        ref = gen(n, L) if kind == "zeros" else gen(n, L, first_line=first)
+        assert (host == ref).all(), kind
+        cfg = configs.probe_config(L)
+        ev = mpc.VPC(cfg)
+        d_s = torch.empty(n, dtype=torch.int16, device=dev)
+        d_c = torch.empty(n, dtype=torch.int8, device=dev)
+        ev.compress_device(buf.data_ptr(), n, d_s.data_ptr(), d_c.data_ptr(),
+                           stream=torch.cuda.current_stream().cuda_stream)
+        ev.sync(); torch.cuda.synchronize()
+        o = oracle.VpcOracle(cfg)
+        sr, cr = o.compress(ref)
+        assert (d_s.cpu().numpy().view(np.uint16) == sr).all() and (d_c.cpu().numpy() == cr).all()
+        assert (ev.stats_vector() == o.stats_vector()).all()
+
+
+def test_full_size_properties(mpc, configs):
+    """Size-independent checks at a BASELINE-scale buffer (no oracle run): counts
+    add up, random data is incompressible, sharding the buffer and merging the
+    statistics equals one pass, repeating a pass doubles every counter."""
+    import torch
+    dev = torch.device("cuda:0")
+    L, n = 64, 32 << 20                      # 2 GiB of lines
+    buf = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    cfg = configs.probe_config(L)
+    for kind in ("random_u32", "mixed"):
+        mpc.synth_fill(buf.data_ptr(), n, L, kind)
+        whole = mpc.VPC(cfg)
+        whole.compress_device(buf.data_ptr(), n)
+        v = whole.stats_vector()
+        assert v[0] == n and v[1] == n * 512
+        K, B = 7, whole.hist_bins
+        hist = v[3 + 6 * K:].reshape(K, B)
+        assert int(hist.sum()) == n
+        sizes = np.arange(B, dtype=np.uint64)
+        assert int((hist * sizes[None, :]).sum()) == int(v[2])
+        if kind == "random_u32":
+            assert int(hist[0, 515]) == n        # every line uncompressed: 512 + 3 id bits
+        # 3 unequal shards on separate handles, merged == whole
+        parts = mpc.VPC(cfg)
+        cuts = [0, n // 3 + 5, n // 2 + 77, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            sh = mpc.VPC(cfg)
+            sh.compress_device(buf.data_ptr() + a * L, b - a)
+            parts.stats_merge(sh.stats_vector())
+            sh.close()
+        assert (parts.stats_vector() == v).all()
+        whole.compress_device(buf.data_ptr(), n)
+        assert (whole.stats_vector() == 2 * v).all()
+        whole.close(); parts.close()
