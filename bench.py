@@ -116,7 +116,10 @@ def main():
         ev = mpc.VPC(configs.probe_config(L), device=local_rank)
     else:
         ev = mpc.BDI(L, device=local_rank)
-    stream = torch.cuda.current_stream()
+    # a real (non-default) stream: the kernel is launched on it through the C ABI and
+    # the HIP events that time it are recorded on the same stream
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     sp = stream.cuda_stream
 
     def step(ev_pair=None):

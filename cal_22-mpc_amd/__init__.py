@@ -42,6 +42,24 @@ class Info(C.Structure):
 _lib = None
 
 
+def _share_host_hip_runtime() -> None:
+    """One HIP runtime per process.  The PyTorch wheel bundles its own
+    libamdhip64.so / libhsa-runtime64.so next to libtorch_hip.so; if libmpc_hip.so
+    brought up the system copy (/opt/rocm) as well, the process would hold two HSA
+    runtimes, PyTorch could no longer see the GPU, and streams / device pointers
+    could not be shared.  Promoting PyTorch's copy to the global symbol scope
+    BEFORE libmpc_hip.so is bound (RTLD_NOW) makes every hip* reference of
+    libmpc_hip.so resolve to that one runtime.  Without PyTorch (the C++ CLI)
+    libmpc_hip.so simply uses the system runtime it is linked against."""
+    try:
+        import torch  # noqa: F401
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib() -> C.CDLL:
     """Load libmpc_hip.so (in-tree).  Raises if it has not been built."""
     global _lib
@@ -49,7 +67,8 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python {HERE}/build.py` "
                               "(there is no fallback implementation)")
-        L = C.CDLL(LIB_PATH)
+        _share_host_hip_runtime()
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL | os.RTLD_NOW)
         H = C.c_void_p
         sigs = {
             "mpc_create_vpc": ([C.c_char_p, C.c_int, C.POINTER(H)], C.c_int),

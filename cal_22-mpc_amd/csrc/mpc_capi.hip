@@ -439,14 +439,17 @@ int mpc_compress_batch_device(mpc_handle *h, const void *d_lines, uint64_t n, ui
   if (!h || (!d_lines && n)) return MPC_E_INVAL;
   if (((uintptr_t)d_lines) & 15u) return set_err(h, MPC_E_INVAL, "device line buffer must be 16-byte aligned");
   HIPCHK(h, hipSetDevice(h->device));
-  return launch(h, d_lines, n, d_sizes, d_sel, hip_stream ? (hipStream_t)hip_stream : h->stream);
+  return launch(h, d_lines, n, d_sizes, d_sel, (hipStream_t)hip_stream);
 }
 
 int mpc_sync(mpc_handle *h)
 {
   if (!h) return MPC_E_INVAL;
   HIPCHK(h, hipSetDevice(h->device));
-  return sync_all(h);
+  int rc = sync_all(h);
+  if (rc != MPC_OK) return rc;
+  HIPCHK(h, hipDeviceSynchronize());   // batches may have been queued on caller streams
+  return MPC_OK;
 }
 
 int mpc_compress_batch(mpc_handle *h, const uint8_t *lines, uint64_t n, uint16_t *sizes, int8_t *sel)

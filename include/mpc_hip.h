@@ -81,9 +81,10 @@ int mpc_compress_batch(mpc_handle *h, const uint8_t *lines, uint64_t n_lines,
                        uint16_t *size_bits_out, int8_t *selected_out);
 
 /* Same, for lines already resident in DEVICE memory (16-byte aligned) and
- * optional DEVICE output arrays; asynchronous on `hip_stream` (a hipStream_t,
- * NULL = the handle's own stream).  Statistics accumulate on the device; call
- * mpc_sync (or mpc_stats_get) before reading outputs.                       */
+ * optional DEVICE output arrays; asynchronous on `hip_stream` (a hipStream_t
+ * passed straight to the launch; NULL = HIP's default stream).  Statistics
+ * accumulate on the device; call mpc_sync (or mpc_stats_get), which wait for the
+ * whole device, before reading outputs.                                     */
 int mpc_compress_batch_device(mpc_handle *h, const void *d_lines, uint64_t n_lines,
                               uint16_t *d_size_bits_out, int8_t *d_selected_out,
                               void *hip_stream);
