@@ -1,412 +1,10 @@
-// mpc_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the per-line evaluator.
+// mpc_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the per-line evaluator other
+// than the fast VPC kernel (mpc_vpc_fast.hip):
 //
-//   vpc_fast_kernel<LPL>   VPC, plane-major scan / root 0 / windowed tables
 //   vpc_generic_kernel     VPC, any configuration the reference can run
-//   bdi_kernel             BDI baseline
-//   synth_*/read_probe     measurement helpers
-//
-// Mapping of the fast kernel (wave64): a line of L bytes is held by LPL = L/16
-// adjacent lanes, 16 bytes (one global_load_dwordx4, fully coalesced) per lane.
-// Lane g of a line owns columns 16g..16g+15 of the residue array, i.e. exactly
-// the 16-bit scanned rows (plane p, group g) for p = 0..7 of the plane-major
-// scan (reference ScanModule.cpp:13-19 with Rows[i]=i/L, Cols[i]=i%L).  All
-// byte arithmetic is SWAR on 32-bit words; cross-lane traffic inside a line is
-// DPP (quad_perm / row_shr / row_shl) -- no LDS, no ballots on the data path.
-//
-// What the stages compute, against the reference (src/compressor/...):
-//   AllZero / AllWordSame      VPCmodules/AllZeroModule.cpp:7-15, AllWordSameModule.cpp:7-21
-//   predictors                 VPCmodules/PredictorModule.cpp:37-173
-//   residue (root first)       VPCmodules/ResidueModule.cpp:12-41
-//   bit-plane + XOR            BitplaneModule.cpp:7-51, XORModule.cpp:5-23: on bytes this is
-//                              g = b ^ (b >> 1) (consecutive) or b ^ (msb ? 0x7f : 0), column 0 untouched
-//   selector (leading zero rows, ties -> later module)   VPC.cpp:366-395
-//   common encoder             VPCmodules/FPCModule.cpp:19-85 (sizes FPCModule.h:55)
-//   decision + id bits         VPC.cpp:397-407
-//   residue statistics         VPC.cpp:417-443, ResidueModule.cpp:43-74
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "mpc_device.h"
-
-typedef unsigned long long u64;
-typedef uint32_t u32;
-
-#define H80 0x80808080u
-#define L7F 0x7f7f7f7fu
-
-// ---------------------------------------------------------------------------
-// DPP helpers
-// ---------------------------------------------------------------------------
-#define QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
-#define DPP_ROW_SHL(n) (0x100 + (n))
-#define DPP_ROW_SHR(n) (0x110 + (n))
-#define DPP_ROW_HALF_MIRROR 0x141
-
-template <int CTRL>
-__device__ __forceinline__ u32 dpp(u32 v)
-{
-  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-}
-
-// Cross-lane operations inside the LPL lanes that hold one line.
-template <int LPL> struct Grp;
-
-template <> struct Grp<4> {
-  static __device__ __forceinline__ u32 prev(u32 v) { return dpp<QP(0, 0, 1, 2)>(v); }   // lane g-1 (g=0: self)
-  static __device__ __forceinline__ u32 next(u32 v) { return dpp<QP(1, 2, 3, 3)>(v); }   // lane g+1 (last: self)
-  static __device__ __forceinline__ u32 first(u32 v) { return dpp<QP(0, 0, 0, 0)>(v); }
-  static __device__ __forceinline__ u32 last(u32 v) { return dpp<QP(3, 3, 3, 3)>(v); }
-  static __device__ __forceinline__ u32 red_or(u32 v) { v |= dpp<QP(1, 0, 3, 2)>(v); v |= dpp<QP(2, 3, 0, 1)>(v); return v; }
-  static __device__ __forceinline__ u32 red_add(u32 v) { v += dpp<QP(1, 0, 3, 2)>(v); v += dpp<QP(2, 3, 0, 1)>(v); return v; }
-  static __device__ __forceinline__ u32 red_min(u32 v) { v = min(v, dpp<QP(1, 0, 3, 2)>(v)); v = min(v, dpp<QP(2, 3, 0, 1)>(v)); return v; }
-};
-
-template <> struct Grp<2> {
-  static __device__ __forceinline__ u32 prev(u32 v) { return dpp<QP(0, 0, 2, 2)>(v); }
-  static __device__ __forceinline__ u32 next(u32 v) { return dpp<QP(1, 1, 3, 3)>(v); }
-  static __device__ __forceinline__ u32 first(u32 v) { return dpp<QP(0, 0, 2, 2)>(v); }
-  static __device__ __forceinline__ u32 last(u32 v) { return dpp<QP(1, 1, 3, 3)>(v); }
-  static __device__ __forceinline__ u32 red_or(u32 v) { return v | dpp<QP(1, 0, 3, 2)>(v); }
-  static __device__ __forceinline__ u32 red_add(u32 v) { return v + dpp<QP(1, 0, 3, 2)>(v); }
-  static __device__ __forceinline__ u32 red_min(u32 v) { return min(v, dpp<QP(1, 0, 3, 2)>(v)); }
-};
-
-template <> struct Grp<8> {
-  // groups are the aligned 8-lane halves of a 16-lane DPP row
-  static __device__ __forceinline__ u32 prev(u32 v) { return dpp<DPP_ROW_SHR(1)>(v); }   // g=0: other group / 0 (caller masks)
-  static __device__ __forceinline__ u32 next(u32 v) { return dpp<DPP_ROW_SHL(1)>(v); }   // g=7: other group / 0 (caller masks)
-  static __device__ __forceinline__ u32 first(u32 v)
-  {
-    u32 q = dpp<QP(0, 0, 0, 0)>(v);          // lane 0 of each quad
-    u32 s = dpp<DPP_ROW_SHR(4)>(q);          // the quad below
-    return (threadIdx.x & 4) ? s : q;
-  }
-  static __device__ __forceinline__ u32 last(u32 v)
-  {
-    u32 q = dpp<QP(3, 3, 3, 3)>(v);
-    u32 s = dpp<DPP_ROW_SHL(4)>(q);
-    return (threadIdx.x & 4) ? q : s;
-  }
-  static __device__ __forceinline__ u32 red_or(u32 v) { v |= dpp<QP(1, 0, 3, 2)>(v); v |= dpp<QP(2, 3, 0, 1)>(v); v |= dpp<DPP_ROW_HALF_MIRROR>(v); return v; }
-  static __device__ __forceinline__ u32 red_add(u32 v) { v += dpp<QP(1, 0, 3, 2)>(v); v += dpp<QP(2, 3, 0, 1)>(v); v += dpp<DPP_ROW_HALF_MIRROR>(v); return v; }
-  static __device__ __forceinline__ u32 red_min(u32 v) { v = min(v, dpp<QP(1, 0, 3, 2)>(v)); v = min(v, dpp<QP(2, 3, 0, 1)>(v)); v = min(v, dpp<DPP_ROW_HALF_MIRROR>(v)); return v; }
-};
-
-// ---------------------------------------------------------------------------
-// SWAR byte arithmetic on 32-bit words
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ u32 bsub(u32 a, u32 b)   // per-byte (a - b) mod 256
-{
-  return ((a | H80) - (b & L7F)) ^ ((a ^ ~b) & H80);
-}
-__device__ __forceinline__ u32 badd(u32 a, u32 b)   // per-byte (a + b) mod 256
-{
-  return ((a & L7F) + (b & L7F)) ^ ((a ^ b) & H80);
-}
-__device__ __forceinline__ u32 fold8(u32 x)          // OR of the 4 bytes
-{
-  x |= x >> 16;
-  x |= x >> 8;
-  return x & 0xffu;
-}
-__device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-__device__ __forceinline__ u32 alignbyte(u32 hi, u32 lo, u32 n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
-__device__ __forceinline__ u32 sum_bytes(u32 x, u32 acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }
-__device__ __forceinline__ u32 sum_sq_bytes(u32 x, u32 acc) { return __builtin_amdgcn_udot4(x, x, acc, false); }
-
-// ---------------------------------------------------------------------------
-// statistics: per-workgroup LDS accumulators, flushed once per workgroup
-// ---------------------------------------------------------------------------
-struct WgStats {
-  u32 *hist;   // [K * bins] (LDS)
-  u64 *sums;   // [2 * K]    (LDS): sum_r, sum_r2
-};
-
-__device__ __forceinline__ void stats_init(const WgStats &s, int K, int bins)
-{
-  for (int i = threadIdx.x; i < K * bins; i += blockDim.x) s.hist[i] = 0;
-  for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) s.sums[i] = 0;
-  __syncthreads();
-}
-
-__device__ __forceinline__ void stats_flush(const WgStats &s, int K, int bins, u64 *g)
-{
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) {
-    u64 v = s.sums[i];
-    if (v) atomicAdd(&g[i], v);
-  }
-  for (int i = threadIdx.x; i < K * bins; i += blockDim.x) {
-    u32 v = s.hist[i];
-    if (v) atomicAdd(&g[2 * K + i], (u64)v);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// fast VPC kernel
-// ---------------------------------------------------------------------------
-
-// Common encoder on this lane's 8 rows (plane 7-j <-> bit j): returns the bits
-// of the non-zero rows and the zero-row mask.  t[4] = transformed residue bytes
-// of columns 16g..16g+15.
-__device__ __forceinline__ u32 encode_rows(const u32 t[4], u32 &zero_mask)
-{
-  // per plane: S = any bit set, T = set in >= 2 columns, U = in >= 3 columns
-  u32 s01 = t[0] | t[1], t01 = t[0] & t[1];
-  u32 s23 = t[2] | t[3], t23 = t[2] & t[3];
-  u32 S = s01 | s23;
-  u32 T = t01 | t23 | (s01 & s23);
-  u32 U = (t01 & s23) | (s01 & t23);
-  // fold the 4 byte lanes (counts add up across bytes)
-  {
-    u32 S2 = S >> 16, T2 = T >> 16, U2 = U >> 16;
-    u32 nU = U | U2 | (T & S2) | (S & T2);
-    u32 nT = T | T2 | (S & S2);
-    S |= S2; T = nT; U = nU;
-  }
-  {
-    u32 S2 = S >> 8, T2 = T >> 8, U2 = U >> 8;
-    u32 nU = U | U2 | (T & S2) | (S & T2);
-    u32 nT = T | T2 | (S & S2);
-    S |= S2; T = nT; U = nU;
-  }
-  S &= 0xffu; T &= 0xffu; U &= 0xffu;
-  const u32 Sf = fold8(s01);   // columns 0..7
-  const u32 Sb = fold8(s23);   // columns 8..15
-  // two ones in adjacent columns c, c+1 (c = 0..14)
-  u32 A = (t[0] & alignbyte(t[1], t[0], 1)) | (t[1] & alignbyte(t[2], t[1], 1)) |
-          (t[2] & alignbyte(t[3], t[2], 1)) | (t[3] & (t[3] >> 8));
-  A = fold8(A);
-  const u32 single = S & ~T;
-  const u32 two = T & ~U & A;
-  const u32 rest = S & ~single & ~two;
-  const u32 both = Sf & Sb;
-  const u32 half = rest & ~both;   // one 8-column half empty: 12 bits
-  const u32 full = rest & both;    // 17 bits
-  zero_mask = ~S & 0xffu;
-  return 7u * __popc(single) + 8u * __popc(two) + 12u * __popc(half) + 17u * __popc(full);
-}
-
-template <int LPL>
-__global__ void __launch_bounds__(256)
-vpc_fast_kernel(const uint4 *__restrict__ lines, u64 n_lines, MpcVpcParams P,
-                uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int L = 16 * LPL;
-  constexpr int W = L / 4;             // words per line
-  const int K = P.M + 1, bins = P.hist_bins;
-  WgStats st;
-  st.sums = reinterpret_cast<u64 *>(smem);
-  st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * K * 8 + 15) / 16));
-  // per-wave scratch for the byte-plane shuffle of ConsecutiveBasePredictor: 64 lanes x 16 B
-  u32 *shuf = reinterpret_cast<u32 *>(smem + 16 * ((2 * K * 8 + 15) / 16) + 16 * ((K * bins * 4 + 15) / 16)) +
-              (threadIdx.x >> 6) * 256;
-  stats_init(st, K, bins);
-
-  const u32 lane = threadIdx.x & 63;
-  const u32 g = lane & (LPL - 1);      // column group inside the line
-  const u32 line_in_wave = lane / LPL;
-  const u64 n_chunks = n_lines * LPL;
-  const u64 stride = (u64)gridDim.x * blockDim.x;
-  const u32 colmask0 = (g == 0) ? 0xffffff00u : 0xffffffffu;   // column 0 is exempt from the XOR stage
-  const u32 *tab = P.tab;
-  const u32 uncomp = 8u * L;
-
-  for (u64 chunk0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); chunk0 < n_chunks; chunk0 += stride) {
-    const u64 chunk = chunk0 + lane;
-    const bool valid = chunk < n_chunks;     // uniform inside a line group
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (valid) v = lines[chunk];
-    const u32 x[4] = {v.x, v.y, v.z, v.w};
-
-    // ---- AllZero / AllWordSame ----
-    const u32 any = Grp<LPL>::red_or(x[0] | x[1] | x[2] | x[3]);
-    const u32 w0 = Grp<LPL>::first(x[0]);
-    const u32 dif = Grp<LPL>::red_or((x[0] ^ w0) | (x[1] ^ w0) | (x[2] ^ w0) | (x[3] ^ w0));
-    const bool is_zero = (any == 0);
-    const bool is_same = P.has_aws && (dif == 0);
-
-    int chosen = -1;
-    u32 size = 0;
-    u32 sum_r = 0, sum_r2 = 0;
-    bool residue_stat = false;
-
-    if (is_zero) {
-      chosen = 0;
-      size = (u32)P.enc_bits[1];
-    } else if (is_same) {
-      chosen = 1;
-      size = 32u + (u32)P.enc_bits[2];
-    }
-    // Skip the prediction modules only when no line of the wave needs them
-    // (wave-uniform branch; DPP needs the whole line group active).
-    const bool need = valid && !is_zero && !is_same;
-    if (__any(need)) {
-      const u32 b0 = w0 & 0xffu;                 // root byte (RootIndex 0)
-      const u32 rootb = b0 * 0x01010101u;
-      u32 best[4] = {0, 0, 0, 0};
-      u32 best_z = 0;
-      int best_q = -1;
-      u32 best_root_r = 0;
-      bool best_cx = false;
-      for (int q = 0; q < P.n_pred; q++) {
-        const MpcFastModule fm = P.fm[q];
-        u32 r[4];
-        u32 root_r = 0;      // residue GetMAE/GetMSE see at the root position
-        if (fm.kind == MPC_FK_ONEBASE) {
-          // predicted = line[0] everywhere; position 0 of the residue array is the raw root
-#pragma unroll
-          for (int e = 0; e < 4; e++) r[e] = bsub(x[e], rootb);
-          if (g == 0) r[0] = (r[0] & 0xffffff00u) | b0;
-        } else if (fm.kind == MPC_FK_CONSEC) {
-          // inp = bytes reordered plane 3,2,1,0 of each word; predicted[i] = inp[i-1]
-          // 4x4 byte transpose of this lane's 4 words: T[k] = byte k of the 4 words
-          const u32 lo01 = perm(x[1], x[0], 0x05010400u), hi01 = perm(x[1], x[0], 0x07030602u);
-          const u32 lo23 = perm(x[3], x[2], 0x05010400u), hi23 = perm(x[3], x[2], 0x07030602u);
-          u32 T[4];
-          T[0] = perm(lo23, lo01, 0x05040100u);
-          T[1] = perm(lo23, lo01, 0x07060302u);
-          T[2] = perm(hi23, hi01, 0x05040100u);
-          T[3] = perm(hi23, hi01, 0x07060302u);
-          // scatter into the shuffled line (per-line L bytes in LDS): byte k of word w -> inp[(3-k)*W + w]
-          u32 *ln = shuf + line_in_wave * W;    // W dwords per line
-#pragma unroll
-          for (int k = 0; k < 4; k++) ln[((3 - k) * W + 4 * g) / 4] = T[k];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          u32 in[4];
-#pragma unroll
-          for (int e = 0; e < 4; e++) in[e] = ln[4 * g + e];
-          __builtin_amdgcn_wave_barrier();
-          u32 carry = Grp<LPL>::prev(in[3]);     // inp[16g-1] lives in the previous lane's last byte
-          u32 p[4];
-          p[0] = alignbyte(in[0], carry, 3);
-          p[1] = alignbyte(in[1], in[0], 3);
-          p[2] = alignbyte(in[2], in[1], 3);
-          p[3] = alignbyte(in[3], in[2], 3);
-          if (g == 0) p[0] &= 0xffffff00u;        // root: predicted byte 0 -> residue[0] = raw root
-#pragma unroll
-          for (int e = 0; e < 4; e++) r[e] = bsub(x[e], p[e]);
-          // predicted[root] = inp[0] = byte 3 of word 0 (PredictorModule.cpp:159-164)
-          root_r = (b0 - (w0 >> 24)) & 0xffu;
-        } else {
-          // base byte from the own / previous dword (v_perm), then +diff or shifts
-          const u32 *t = tab + fm.tab_off;
-          const u32 xm1 = Grp<LPL>::prev(x[3]);   // previous lane's last dword (unused for g == 0)
-          u32 p[4];
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const u32 prevw = (e == 0) ? xm1 : x[e - 1];
-            const u32 b = perm(x[e], prevw, t[4 * g + e]);
-            const u32 c1 = t[W + 4 * g + e];
-            if (fm.kind == MPC_FK_DIFF) {
-              p[e] = badd(b, c1);
-            } else {
-              const u32 c2 = t[2 * W + 4 * g + e];
-              p[e] = (((b << fm.ls1) >> fm.rs1) & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
-            }
-          }
-          if (g == 0) p[0] &= 0xffffff00u;
-#pragma unroll
-          for (int e = 0; e < 4; e++) r[e] = bsub(x[e], p[e]);
-        }
-        // leading zero rows of the scanned array.  The first non-zero row of the
-        // XORed planes equals that of the raw residue planes, so
-        // the selector works on r directly.
-        const u32 S = fold8(r[0] | r[1] | r[2] | r[3]);
-        const u32 O = Grp<LPL>::red_or(S);
-        u32 z;
-        if (O == 0) {
-          z = 8u * LPL;
-        } else {
-          const u32 p_star = (u32)__clz((int)O) - 24u;          // first non-zero plane (0 = MSB)
-          const u32 has = (S >> (7u - p_star)) & 1u;
-          const u32 g_star = Grp<LPL>::red_min(has ? g : (u32)LPL);
-          z = LPL * p_star + g_star;
-        }
-        if (best_z <= z) {     // ties go to the later module (VPC.cpp:389)
-          best_z = z;
-          best_q = q;
-          best_root_r = root_r;
-          best_cx = fm.cx != 0;
-#pragma unroll
-          for (int e = 0; e < 4; e++) best[e] = r[e];
-        }
-      }
-
-      u32 enc = 0;
-      if (best_q >= 0) {
-        // XOR stage of the winner, on bytes
-        const bool cx = best_cx;
-        u32 t[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const u32 cm = (e == 0) ? colmask0 : 0xffffffffu;
-          u32 f;
-          if (cx) {
-            f = (best[e] >> 1) & L7F;
-          } else {
-            const u32 m = (best[e] >> 7) & 0x01010101u;
-            f = (m << 7) - m;   // 0x7f where the byte's MSB is set
-          }
-          t[e] = best[e] ^ (f & cm);
-        }
-        u32 Z;
-        u32 bits = encode_rows(t, Z);
-        // zero-row runs in row order r = plane * LPL + g
-        const u32 Zprev_lane = Grp<LPL>::prev(Z), Zlast = Grp<LPL>::last(Z);
-        const u32 Znext_lane = Grp<LPL>::next(Z), Zfirst = Grp<LPL>::first(Z);
-        const u32 prevZ = (g == 0) ? (Zlast >> 1) : Zprev_lane;
-        const u32 nextZ = (g == LPL - 1) ? ((Zfirst << 1) & 0xffu) : Znext_lane;
-        const u32 starts = Z & ~prevZ;
-        bits += 4u * __popc(starts) + 3u * __popc(starts & nextZ);
-        enc = Grp<LPL>::red_add(bits);
-      }
-      if (need) {
-        residue_stat = true;
-        if (best_q >= 0 && enc < uncomp) {
-          chosen = P.start + best_q;
-          size = enc;
-          // residues over all positions; the root position holds best_root_r, not the raw root
-          u32 rr[4] = {best[0], best[1], best[2], best[3]};
-          if (g == 0) rr[0] = (rr[0] & 0xffffff00u) | best_root_r;
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            sum_r = sum_bytes(rr[e], sum_r);
-            sum_r2 = sum_sq_bytes(rr[e], sum_r2);
-          }
-        } else {
-          chosen = -1;
-          size = (best_q >= 0) ? uncomp : 0u;   // no prediction module: empty array encodes to 0 bits
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            sum_r = sum_bytes(x[e], sum_r);
-            sum_r2 = sum_sq_bytes(x[e], sum_r2);
-          }
-        }
-        size += (u32)P.enc_bits[chosen + 1];
-      }
-      sum_r = Grp<LPL>::red_add(sum_r);
-      sum_r2 = Grp<LPL>::red_add(sum_r2);
-    }
-
-    // ---- per-line results: one lane per line ----
-    if (valid && g == 0) {
-      const u64 line = chunk / LPL;
-      if (sizes_out) sizes_out[line] = (uint16_t)size;
-      if (sel_out) sel_out[line] = (int8_t)chosen;
-      const int k = chosen + 1;
-      atomicAdd(&st.hist[k * bins + (int)size], 1u);
-      if (residue_stat) {
-        atomicAdd(&st.sums[k], (u64)sum_r);
-        atomicAdd(&st.sums[K + k], (u64)sum_r2);
-      }
-    }
-  }
-  stats_flush(st, K, bins, gstats);
-}
+//   bdi_kernel             BDI baseline (reference src/compressor/BDI.cpp)
+//   synth_kernel / read_probe_kernel   measurement helpers
+#include "mpc_kernel_common.h"
 
 // ---------------------------------------------------------------------------
 // generic VPC kernel: one lane per line, byte loops, any configuration.
@@ -702,28 +300,6 @@ __global__ void __launch_bounds__(256) read_probe_kernel(const uint4 *__restrict
 // ---------------------------------------------------------------------------
 // host-callable launchers (used by mpc_capi.hip)
 // ---------------------------------------------------------------------------
-static inline size_t vpc_stats_smem(int K, int bins)
-{
-  return 16 * (size_t)((2 * K * 8 + 15) / 16) + 16 * (size_t)((K * bins * 4 + 15) / 16);
-}
-
-extern "C" hipError_t mpc_launch_vpc_fast(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
-                                          int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
-{
-  const int K = P->M + 1;
-  const int block = 256;
-  const size_t smem = vpc_stats_smem(K, P->hist_bins) + (size_t)(block / 64) * 1024;
-  const uint4 *l = static_cast<const uint4 *>(d_lines);
-  switch (P->L) {
-  case 32: hipLaunchKernelGGL(vpc_fast_kernel<2>, dim3(grid), dim3(block), smem, stream, l, n_lines, *P, d_sizes, d_sel, d_stats); break;
-  case 64: hipLaunchKernelGGL(vpc_fast_kernel<4>, dim3(grid), dim3(block), smem, stream, l, n_lines, *P, d_sizes, d_sel, d_stats); break;
-  case 128: hipLaunchKernelGGL(vpc_fast_kernel<8>, dim3(grid), dim3(block), smem, stream, l, n_lines, *P, d_sizes, d_sel, d_stats); break;
-  default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-extern "C" size_t mpc_vpc_fast_smem(const MpcVpcParams *P) { return vpc_stats_smem(P->M + 1, P->hist_bins) + 4 * 1024; }
 extern "C" size_t mpc_vpc_generic_smem(const MpcVpcParams *P) { return vpc_stats_smem(P->M + 1, P->hist_bins); }
 
 extern "C" hipError_t mpc_launch_vpc_generic(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,

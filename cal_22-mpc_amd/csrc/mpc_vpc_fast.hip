@@ -1,0 +1,457 @@
+// mpc_vpc_fast.hip -- the hot kernel: VPC multi-prediction evaluation of lines whose
+// configuration has the plane-major scan, RootIndex 0 and "windowed" predictor
+// tables (see mpc_config.h: build_vpc_plan).  gfx950 / wave64 only.
+//
+// Mapping: a line of L bytes is held by LPL = L/16 adjacent lanes, 16 bytes (one
+// global_load_dwordx4, fully coalesced) per lane.  Lane g of a line owns columns
+// 16g..16g+15 of the residue array, i.e. exactly the 16-bit scanned rows
+// (plane p, group g), p = 0..7, of the plane-major scan (reference
+// ScanModule.cpp:13-19 with Rows[i]=i/L, Cols[i]=i%L).  All byte arithmetic is
+// SWAR on 32-bit words (v_perm_b32 / v_alignbyte / v_sad_u8 / v_dot4_u32_u8);
+// cross-lane traffic inside a line is DPP.  Statistics are run-length
+// accumulated per lane and only reach LDS / global atomics when the
+// (cluster, size) key changes.
+//
+// What the stages compute, against the reference (src/compressor/...):
+//   AllZero / AllWordSame      VPCmodules/AllZeroModule.cpp:7-15, AllWordSameModule.cpp:7-21
+//   predictors                 VPCmodules/PredictorModule.cpp:37-173
+//   residue (root first)       VPCmodules/ResidueModule.cpp:12-41
+//   bit-plane + XOR            BitplaneModule.cpp:7-51, XORModule.cpp:5-23; on bytes:
+//                              g = b ^ (b >> 1) (consecutive) or b ^ (msb ? 0x7f : 0), column 0 untouched
+//   selector (leading zero rows, ties -> later module)   VPC.cpp:366-395
+//   common encoder             VPCmodules/FPCModule.cpp:19-85 (sizes FPCModule.h:55)
+//   decision + id bits         VPC.cpp:397-407
+//   residue statistics         VPC.cpp:417-443, ResidueModule.cpp:43-74
+//
+// The kernel is a template over the sequence of predictor forms so that the
+// module loop is unrolled and every table lives in registers; configurations
+// whose sequence has no instantiation run the same code with a runtime loop.
+#include "mpc_kernel_common.h"
+
+// ---------------------------------------------------------------------------
+// common encoder on this lane's 8 rows (bit j <-> plane 7-j).  t[4] = transformed
+// residue bytes of columns 16g..16g+15.  Returns the bits of the non-zero rows.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 encode_rows(const u32 t[4], u32 &zero_mask)
+{
+  // per plane: S = any bit set, T = set in >= 2 columns, U = in >= 3 columns
+  u32 s01 = t[0] | t[1], t01 = t[0] & t[1];
+  u32 s23 = t[2] | t[3], t23 = t[2] & t[3];
+  u32 S = s01 | s23;
+  u32 T = t01 | t23 | (s01 & s23);
+  u32 U = (t01 & s23) | (s01 & t23);
+  {   // fold the 4 byte lanes: counts add up across bytes
+    u32 S2 = S >> 16, T2 = T >> 16, U2 = U >> 16;
+    u32 nU = U | U2 | (T & S2) | (S & T2);
+    u32 nT = T | T2 | (S & S2);
+    S |= S2; T = nT; U = nU;
+  }
+  {
+    u32 S2 = S >> 8, T2 = T >> 8, U2 = U >> 8;
+    u32 nU = U | U2 | (T & S2) | (S & T2);
+    u32 nT = T | T2 | (S & S2);
+    S |= S2; T = nT; U = nU;
+  }
+  S &= 0xffu; T &= 0xffu; U &= 0xffu;
+  const u32 Sf = fold8(s01);   // columns 0..7
+  const u32 Sb = fold8(s23);   // columns 8..15
+  // two ones in adjacent columns c, c+1 (c = 0..14)
+  u32 A = (t[0] & alignbyte(t[1], t[0], 1)) | (t[1] & alignbyte(t[2], t[1], 1)) |
+          (t[2] & alignbyte(t[3], t[2], 1)) | (t[3] & (t[3] >> 8));
+  A = fold8(A);
+  const u32 single = S & ~T;             // exactly one 1: 7 bits
+  const u32 two = T & ~U & A;            // exactly two, adjacent: 8 bits
+  const u32 rest = S & ~single & ~two;
+  const u32 both = Sf & Sb;
+  const u32 half = rest & ~both;         // one 8-column half empty: 12 bits
+  const u32 full = rest & both;          // 17 bits
+  zero_mask = ~S & 0xffu;
+  return 7u * __popc(single) + 8u * __popc(two) + 12u * __popc(half) + 17u * __popc(full);
+}
+
+struct WinTab { u32 sel[4], c1[4], c2[4]; };
+
+template <int LPL>
+struct LineCtx {
+  u32 x[4];    // this lane's 16 bytes
+  u32 w0;      // word 0 of the line
+  u32 b0;      // byte 0 = root (RootIndex 0)
+  u32 rootb;   // root replicated into 4 bytes
+  u32 xm1;     // previous lane's last word (garbage for g == 0, never selected)
+  u32 g;
+};
+
+struct Best {
+  u32 r[4];
+  u32 z;
+  int q;
+  u32 root_r;
+  u32 cx;
+};
+
+// 4x4 transpose of 32-bit words across the 4 lanes of a quad: out lane g, slot e
+// = in lane e, slot g.
+__device__ __forceinline__ void quad_transpose(u32 U[4], u32 lane)
+{
+  const bool o1 = lane & 1, o2 = lane & 2;
+  {
+    u32 s0 = o1 ? U[0] : U[1], s1 = o1 ? U[2] : U[3];
+    u32 r0 = dpp<QP(1, 0, 3, 2)>(s0), r1 = dpp<QP(1, 0, 3, 2)>(s1);
+    U[0] = o1 ? r0 : U[0]; U[1] = o1 ? U[1] : r0;
+    U[2] = o1 ? r1 : U[2]; U[3] = o1 ? U[3] : r1;
+  }
+  {
+    u32 s0 = o2 ? U[0] : U[2], s1 = o2 ? U[1] : U[3];
+    u32 r0 = dpp<QP(2, 3, 0, 1)>(s0), r1 = dpp<QP(2, 3, 0, 1)>(s1);
+    U[0] = o2 ? r0 : U[0]; U[2] = o2 ? U[2] : r0;
+    U[1] = o2 ? r1 : U[1]; U[3] = o2 ? U[3] : r1;
+  }
+}
+
+// Residue bytes (root first == natural order for RootIndex 0) of one module for
+// this lane's 16 columns; root_r = residue GetMAE/GetMSE see at the root.
+template <int LPL, int KIND>
+__device__ __forceinline__ void module_residue(const LineCtx<LPL> &c, const MpcFastModule &fm, const WinTab &wt,
+                                               u32 *shuf_line, u32 r[4], u32 &root_r)
+{
+  constexpr int W = 4 * LPL;
+  root_r = 0;
+  if constexpr (KIND == MPC_FK_ONEBASE) {
+    // predicted = line[0] everywhere; position 0 of the residue array is the raw root
+#pragma unroll
+    for (int e = 0; e < 4; e++) r[e] = bsub(c.x[e], c.rootb);
+    if (c.g == 0) r[0] = (r[0] & 0xffffff00u) | c.b0;
+  } else if constexpr (KIND == MPC_FK_CONSEC) {
+    // inp = bytes reordered plane 3,2,1,0 of each word; predicted[i] = inp[i-1].
+    // 4x4 byte transpose of this lane's words: T[k] = byte k of the 4 words
+    const u32 lo01 = perm(c.x[1], c.x[0], 0x05010400u), hi01 = perm(c.x[1], c.x[0], 0x07030602u);
+    const u32 lo23 = perm(c.x[3], c.x[2], 0x05010400u), hi23 = perm(c.x[3], c.x[2], 0x07030602u);
+    u32 in[4];
+    if constexpr (LPL == 4) {
+      // lane g needs byte (3-g) of all 16 words: slot j <- T[3-j], then transpose the quad
+      in[3] = perm(lo23, lo01, 0x05040100u);
+      in[2] = perm(lo23, lo01, 0x07060302u);
+      in[1] = perm(hi23, hi01, 0x05040100u);
+      in[0] = perm(hi23, hi01, 0x07060302u);
+      quad_transpose(in, c.g);
+    } else {
+      // general LPL: scatter into the shuffled line in LDS (byte k of word w -> inp[(3-k)*W + w])
+      u32 T[4];
+      T[0] = perm(lo23, lo01, 0x05040100u);
+      T[1] = perm(lo23, lo01, 0x07060302u);
+      T[2] = perm(hi23, hi01, 0x05040100u);
+      T[3] = perm(hi23, hi01, 0x07060302u);
+#pragma unroll
+      for (int k = 0; k < 4; k++) shuf_line[((3 - k) * W + 4 * c.g) / 4] = T[k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int e = 0; e < 4; e++) in[e] = shuf_line[4 * c.g + e];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    const u32 carry = Grp<LPL>::prev(in[3]);     // inp[16g-1]: last byte of the previous lane
+    u32 p0 = alignbyte(in[0], carry, 3);
+    if (c.g == 0) p0 &= 0xffffff00u;            // root: predicted byte 0 -> residue[0] = raw root
+    r[0] = bsub(c.x[0], p0);
+    r[1] = bsub(c.x[1], alignbyte(in[1], in[0], 3));
+    r[2] = bsub(c.x[2], alignbyte(in[2], in[1], 3));
+    r[3] = bsub(c.x[3], alignbyte(in[3], in[2], 3));
+    // predicted[root] = inp[0] = byte 3 of word 0 (PredictorModule.cpp:159-164)
+    root_r = (c.b0 - (c.w0 >> 24)) & 0xffu;
+  } else {
+    // base byte from the own / previous word (v_perm), then + diff or per-byte shifts;
+    // the table forces the predicted root byte to 0
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const u32 prevw = (e == 0) ? c.xm1 : c.x[e - 1];
+      const u32 b = perm(c.x[e], prevw, wt.sel[e]);
+      u32 p;
+      if constexpr (KIND == MPC_FK_DIFF)
+        p = badd(b, wt.c1[e]);
+      else
+        p = (((b << fm.ls1) >> fm.rs1) & wt.c1[e]) | (((b << fm.ls2) >> fm.rs2) & wt.c2[e]);
+      r[e] = bsub(c.x[e], p);
+    }
+  }
+}
+
+// leading zero rows of the scanned array.  The first non-zero row of the XORed
+// planes equals that of the raw residue planes (DESIGN.md "Selector on raw
+// residues"), so the selector works on r directly.
+template <int LPL>
+__device__ __forceinline__ u32 leading_zero_rows(const u32 r[4], u32 g)
+{
+  const u32 S = fold8(r[0] | r[1] | r[2] | r[3]);
+  const u32 O = Grp<LPL>::red_or(S);
+  const u32 p_star = (u32)__clz((int)O) - 24u;          // first non-zero plane (0 = MSB); 8 if O == 0
+  const u32 has = (S << p_star) & 0x80u;
+  const u32 g_star = Grp<LPL>::red_min(has ? g : (u32)LPL);
+  return O ? LPL * p_star + g_star : 8u * LPL;
+}
+
+template <int LPL, int KIND>
+__device__ __forceinline__ void eval_module(const LineCtx<LPL> &c, const MpcFastModule &fm, const WinTab &wt,
+                                            u32 *shuf_line, int q, Best &best)
+{
+  u32 r[4], root_r;
+  module_residue<LPL, KIND>(c, fm, wt, shuf_line, r, root_r);
+  const u32 z = leading_zero_rows<LPL>(r, c.g);
+  if (best.z <= z) {     // ties go to the later module (VPC.cpp:389)
+    best.z = z;
+    best.q = q;
+    best.root_r = root_r;
+    best.cx = (u32)fm.cx;
+#pragma unroll
+    for (int e = 0; e < 4; e++) best.r[e] = r[e];
+  }
+}
+
+template <int LPL, int Q>
+__device__ __forceinline__ void eval_all(const LineCtx<LPL> &, const MpcVpcParams &, const WinTab *, u32 *, Best &) {}
+
+template <int LPL, int Q, int KIND, int... REST>
+__device__ __forceinline__ void eval_all(const LineCtx<LPL> &c, const MpcVpcParams &P, const WinTab *wt,
+                                         u32 *shuf_line, Best &best)
+{
+  eval_module<LPL, KIND>(c, P.fm[Q], wt[Q], shuf_line, Q, best);
+  eval_all<LPL, Q + 1, REST...>(c, P, wt, shuf_line, best);
+}
+
+__device__ __forceinline__ void load_wintab(const u32 *tab, const MpcFastModule &fm, int W, u32 g, WinTab &wt)
+{
+  const u32 *t = tab + fm.tab_off;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    wt.sel[e] = t[4 * g + e];
+    wt.c1[e] = t[W + 4 * g + e];
+    wt.c2[e] = t[2 * W + 4 * g + e];
+  }
+}
+
+// run-length statistics of one lane (only lane g == 0 of a line uses them)
+struct RunStats {
+  u32 key;     // (cluster + 1) << 16 | size
+  u32 cnt;
+  u32 acc_r, acc_r2;
+};
+
+__device__ __forceinline__ void run_flush(const RunStats &rs, const WgStats &st, int K, int bins)
+{
+  if (rs.cnt) {
+    const int k = (int)(rs.key >> 16);
+    atomicAdd(&st.hist[k * bins + (int)(rs.key & 0xffffu)], rs.cnt);
+    if (rs.acc_r | rs.acc_r2) {
+      atomicAdd(&st.sums[k], (u64)rs.acc_r);
+      atomicAdd(&st.sums[K + k], (u64)rs.acc_r2);
+    }
+  }
+}
+
+template <int LPL, int... KINDS>
+__global__ void __launch_bounds__(256)
+vpc_fast_kernel(const uint4 *__restrict__ lines, u64 n_lines, MpcVpcParams P,
+                uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int L = 16 * LPL;
+  constexpr int W = L / 4;             // words per line
+  constexpr int NPT = sizeof...(KINDS); // 0: module sequence known only at run time
+  constexpr int kinds[NPT > 0 ? NPT : 1] = {KINDS...};
+  const int K = P.M + 1, bins = P.hist_bins;
+  WgStats st;
+  st.sums = reinterpret_cast<u64 *>(smem);
+  st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * K * 8 + 15) / 16));
+  // per-wave scratch for the byte-plane shuffle when LPL != 4: 64 lanes x 16 B
+  u32 *shuf = reinterpret_cast<u32 *>(smem + vpc_stats_smem(K, bins)) + (threadIdx.x >> 6) * 256;
+  stats_init(st, K, bins);
+
+  const u32 lane = threadIdx.x & 63;
+  const u32 g = lane & (LPL - 1);      // column group inside the line
+  u32 *shuf_line = shuf + (lane / LPL) * W;
+  const u64 n_chunks = n_lines * LPL;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  const u32 colmask0 = (g == 0) ? 0xffffff00u : 0xffffffffu;   // column 0 is exempt from the XOR stage
+  const u32 uncomp = 8u * L;
+  const int n_pred = NPT > 0 ? NPT : P.n_pred;
+  const u32 enc_zero = (u32)P.enc_bits[1], enc_same = 32u + (u32)P.enc_bits[2], enc_unc = (u32)P.enc_bits[0];
+
+  // loop-invariant predictor tables in registers (compile-time sequence only)
+  WinTab wt[NPT > 0 ? NPT : 1];
+  if constexpr (NPT > 0) {
+#pragma unroll
+    for (int q = 0; q < NPT; q++)
+      if (kinds[q] == MPC_FK_DIFF || kinds[q] == MPC_FK_WEIGHT) load_wintab(P.tab, P.fm[q], W, g, wt[q]);
+  }
+
+  RunStats rs = {0xffffffffu, 0, 0, 0};
+
+  u64 chunk0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+  uint4 vnext = make_uint4(0, 0, 0, 0);
+  if (chunk0 + lane < n_chunks) vnext = lines[chunk0 + lane];
+  for (; chunk0 < n_chunks; chunk0 += stride) {
+    const u64 chunk = chunk0 + lane;
+    const bool valid = chunk < n_chunks;     // uniform inside a line group
+    const uint4 v = vnext;
+    vnext = make_uint4(0, 0, 0, 0);
+    if (chunk + stride < n_chunks) vnext = lines[chunk + stride];   // prefetch the next iteration
+
+    LineCtx<LPL> c;
+    c.x[0] = v.x; c.x[1] = v.y; c.x[2] = v.z; c.x[3] = v.w;
+    c.g = g;
+
+    // ---- AllZero / AllWordSame ----
+    const u32 any = Grp<LPL>::red_or(c.x[0] | c.x[1] | c.x[2] | c.x[3]);
+    c.w0 = Grp<LPL>::first(c.x[0]);
+    const u32 dif = Grp<LPL>::red_or((c.x[0] ^ c.w0) | (c.x[1] ^ c.w0) | (c.x[2] ^ c.w0) | (c.x[3] ^ c.w0));
+    const bool is_zero = (any == 0);
+    const bool is_same = P.has_aws && (dif == 0);
+
+    int chosen = is_zero ? 0 : 1;
+    u32 size = is_zero ? enc_zero : enc_same;
+    u32 sum_r = 0, sum_r2 = 0;
+
+    // Skip the prediction modules only when no line of the wave needs them
+    // (wave-uniform branch; DPP needs every lane of a line group active).
+    const bool need = valid && !is_zero && !is_same;
+    if (__any(need)) {
+      c.b0 = c.w0 & 0xffu;
+      c.rootb = c.b0 * 0x01010101u;
+      c.xm1 = Grp<LPL>::prev(c.x[3]);
+      Best best;
+      best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
+      best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
+      if constexpr (NPT > 0) {
+        eval_all<LPL, 0, KINDS...>(c, P, wt, shuf_line, best);
+      } else {
+        for (int q = 0; q < n_pred; q++) {
+          const MpcFastModule fm = P.fm[q];
+          WinTab w;
+          switch (fm.kind) {
+          case MPC_FK_ONEBASE: eval_module<LPL, MPC_FK_ONEBASE>(c, fm, w, shuf_line, q, best); break;
+          case MPC_FK_CONSEC: eval_module<LPL, MPC_FK_CONSEC>(c, fm, w, shuf_line, q, best); break;
+          case MPC_FK_DIFF: load_wintab(P.tab, fm, W, g, w); eval_module<LPL, MPC_FK_DIFF>(c, fm, w, shuf_line, q, best); break;
+          default: load_wintab(P.tab, fm, W, g, w); eval_module<LPL, MPC_FK_WEIGHT>(c, fm, w, shuf_line, q, best); break;
+          }
+        }
+      }
+
+      u32 enc = 0;
+      if (n_pred > 0) {
+        // XOR stage of the winner, on bytes
+        u32 t[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const u32 m = (best.r[e] >> 7) & 0x01010101u;
+          const u32 f = best.cx ? ((best.r[e] >> 1) & L7F) : ((m << 7) - m);   // b>>1, or 0x7f where the MSB is set
+          t[e] = best.r[e] ^ (e == 0 ? (f & colmask0) : f);
+        }
+        u32 Z;
+        u32 bits = encode_rows(t, Z);
+        // zero-row runs in row order r = plane * LPL + g: 4 bits per run, 7 if longer than one row
+        const u32 Zprev_lane = Grp<LPL>::prev(Z), Zlast = Grp<LPL>::last(Z);
+        const u32 Znext_lane = Grp<LPL>::next(Z), Zfirst = Grp<LPL>::first(Z);
+        const u32 prevZ = (g == 0) ? (Zlast >> 1) : Zprev_lane;
+        const u32 nextZ = (g == LPL - 1) ? ((Zfirst << 1) & 0xffu) : Znext_lane;
+        const u32 starts = Z & ~prevZ;
+        bits += 4u * __popc(starts) + 3u * __popc(starts & nextZ);
+        enc = Grp<LPL>::red_add(bits);
+      }
+      // residues over all positions: the winner's (root position holds best.root_r, not
+      // the raw root), or the raw bytes when the line stays uncompressed
+      const bool keep = (n_pred > 0) && (enc < uncomp);
+      u32 rr[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) rr[e] = keep ? best.r[e] : c.x[e];
+      if (keep && g == 0) rr[0] = (rr[0] & 0xffffff00u) | best.root_r;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        sum_r = sum_bytes(rr[e], sum_r);
+        sum_r2 = sum_sq_bytes(rr[e], sum_r2);
+      }
+      sum_r = Grp<LPL>::red_add(sum_r);
+      sum_r2 = Grp<LPL>::red_add(sum_r2);
+      if (need) {
+        chosen = keep ? P.start + best.q : -1;
+        // no prediction module: the empty array encodes to 0 bits, cluster -1 (VPC.cpp:397-407)
+        size = keep ? enc : (n_pred > 0 ? uncomp : 0u);
+        size += keep ? (u32)P.enc_bits[chosen + 1] : enc_unc;
+      } else {
+        sum_r = 0;
+        sum_r2 = 0;
+      }
+    }
+
+    // ---- per-line results: one lane per line ----
+    if (valid && g == 0) {
+      const u64 line = chunk / LPL;
+      if (sizes_out) sizes_out[line] = (uint16_t)size;
+      if (sel_out) sel_out[line] = (int8_t)chosen;
+      const u32 key = ((u32)(chosen + 1) << 16) | size;
+      if (key != rs.key || rs.cnt == 255u) {
+        run_flush(rs, st, K, bins);
+        rs.key = key;
+        rs.cnt = 0;
+        rs.acc_r = 0;
+        rs.acc_r2 = 0;
+      }
+      rs.cnt++;
+      rs.acc_r += sum_r;
+      rs.acc_r2 += sum_r2;
+    }
+  }
+  run_flush(rs, st, K, bins);
+  stats_flush(st, K, bins, gstats);
+}
+
+// ---------------------------------------------------------------------------
+// launcher: pick the instantiation that matches the configuration's sequence
+// ---------------------------------------------------------------------------
+#define OB MPC_FK_ONEBASE
+#define CS MPC_FK_CONSEC
+#define DF MPC_FK_DIFF
+#define WT MPC_FK_WEIGHT
+
+template <int... KINDS>
+static bool seq_matches(const MpcVpcParams *P)
+{
+  constexpr int n = sizeof...(KINDS);
+  const int kinds[n > 0 ? n : 1] = {KINDS...};
+  if (P->n_pred != n) return false;
+  for (int q = 0; q < n; q++)
+    if (P->fm[q].kind != kinds[q]) return false;
+  return true;
+}
+
+template <int... KINDS>
+static hipError_t launch_seq(const uint4 *l, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes, int8_t *d_sel,
+                             u64 *d_stats, int grid, size_t smem, hipStream_t stream)
+{
+  switch (P->L) {
+  case 32: hipLaunchKernelGGL((vpc_fast_kernel<2, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines, *P, d_sizes, d_sel, d_stats); break;
+  case 64: hipLaunchKernelGGL((vpc_fast_kernel<4, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines, *P, d_sizes, d_sel, d_stats); break;
+  case 128: hipLaunchKernelGGL((vpc_fast_kernel<8, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines, *P, d_sizes, d_sel, d_stats); break;
+  default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+extern "C" size_t mpc_vpc_fast_smem(const MpcVpcParams *P) { return vpc_stats_smem(P->M + 1, P->hist_bins) + 4 * 1024; }
+
+extern "C" hipError_t mpc_launch_vpc_fast(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
+                                          int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
+{
+  const size_t smem = mpc_vpc_fast_smem(P);
+  const uint4 *l = static_cast<const uint4 *>(d_lines);
+#define TRY_SEQ(...)                                                                                  \
+  if (seq_matches<__VA_ARGS__>(P)) return launch_seq<__VA_ARGS__>(l, n_lines, P, d_sizes, d_sel, d_stats, grid, smem, stream)
+  TRY_SEQ(OB, CS, DF, WT);   // the 4-predictor "probe" sequence
+  TRY_SEQ(OB, CS);
+  TRY_SEQ(OB);
+  TRY_SEQ(CS);
+  TRY_SEQ(DF);
+  TRY_SEQ(WT);
+#undef TRY_SEQ
+  return launch_seq<>(l, n_lines, P, d_sizes, d_sel, d_stats, grid, smem, stream);   // run-time sequence
+}
