@@ -70,6 +70,8 @@ __device__ __forceinline__ u32 encode_rows(const u32 t[4], u32 &zero_mask)
 }
 
 struct WinTab { u32 sel[4], c1[4], c2[4]; };
+// the same tables for (column group 0, word g): what lane g needs for the row-0 prefilter
+struct WinTab0 { u32 sel, c1, c2; };
 
 template <int LPL>
 struct LineCtx {
@@ -79,14 +81,6 @@ struct LineCtx {
   u32 rootb;   // root replicated into 4 bytes
   u32 xm1;     // previous lane's last word (garbage for g == 0, never selected)
   u32 g;
-};
-
-struct Best {
-  u32 r[4];
-  u32 z;
-  int q;
-  u32 root_r;
-  u32 cx;
 };
 
 // 4x4 transpose of 32-bit words across the 4 lanes of a quad: out lane g, slot e
@@ -106,6 +100,17 @@ __device__ __forceinline__ void quad_transpose(u32 U[4], u32 lane)
     U[0] = o2 ? r0 : U[0]; U[2] = o2 ? U[2] : r0;
     U[1] = o2 ? r1 : U[1]; U[3] = o2 ? U[3] : r1;
   }
+}
+
+// predicted word from the own / previous word (v_perm) + diff constant or per-byte shifts
+template <int KIND>
+__device__ __forceinline__ u32 window_predict(u32 own, u32 prevw, u32 sel, u32 c1, u32 c2, const MpcFastModule &fm)
+{
+  const u32 b = perm(own, prevw, sel);
+  if constexpr (KIND == MPC_FK_DIFF)
+    return badd(b, c1);
+  else
+    return (((b << fm.ls1) >> fm.rs1) & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
 }
 
 // Residue bytes (root first == natural order for RootIndex 0) of one module for
@@ -161,62 +166,58 @@ __device__ __forceinline__ void module_residue(const LineCtx<LPL> &c, const MpcF
     // predicted[root] = inp[0] = byte 3 of word 0 (PredictorModule.cpp:159-164)
     root_r = (c.b0 - (c.w0 >> 24)) & 0xffu;
   } else {
-    // base byte from the own / previous word (v_perm), then + diff or per-byte shifts;
-    // the table forces the predicted root byte to 0
+    // the table forces the predicted root byte to 0, so residue[0] = raw root
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const u32 prevw = (e == 0) ? c.xm1 : c.x[e - 1];
-      const u32 b = perm(c.x[e], prevw, wt.sel[e]);
-      u32 p;
-      if constexpr (KIND == MPC_FK_DIFF)
-        p = badd(b, wt.c1[e]);
-      else
-        p = (((b << fm.ls1) >> fm.rs1) & wt.c1[e]) | (((b << fm.ls2) >> fm.rs2) & wt.c2[e]);
-      r[e] = bsub(c.x[e], p);
+      r[e] = bsub(c.x[e], window_predict<KIND>(c.x[e], prevw, wt.sel[e], wt.c1[e], wt.c2[e], fm));
     }
   }
 }
 
+// ---- row-0 prefilter (LPL == 4) ---------------------------------------------
+// A module other than the last one can only win the selector with at least one
+// leading zero row (ties go to the later module, VPC.cpp:389), i.e. only if the
+// MSBs of residue bytes 0..15 are all clear.  Lane g of a line evaluates word g of
+// column group 0 (y = that word, yprev = word g-1); returns the lane's MSB flags.
+struct Pre4 {
+  u32 y, yprev;
+  u32 t3, t3prev;   // byte 3 of this lane's 4 words / of the previous lane's (ConsecutiveBase)
+};
+
+template <int KIND>
+__device__ __forceinline__ u32 row0_msbs(const LineCtx<4> &c, const Pre4 &p, const MpcFastModule &fm, const WinTab0 &w0)
+{
+  u32 pred;
+  if constexpr (KIND == MPC_FK_ONEBASE) {
+    pred = c.rootb;
+  } else if constexpr (KIND == MPC_FK_CONSEC) {
+    pred = alignbyte(p.t3, p.t3prev, 3);   // inp[4g-1 .. 4g+2]
+  } else {
+    pred = window_predict<KIND>(p.y, p.yprev, w0.sel, w0.c1, w0.c2, fm);
+  }
+  if (c.g == 0) pred &= 0xffffff00u;       // byte 0 of the residue array is the raw root
+  return bsub(p.y, pred) & H80;
+}
+
 // leading zero rows of the scanned array.  The first non-zero row of the XORed
 // planes equals that of the raw residue planes (DESIGN.md "Selector on raw
-// residues"), so the selector works on r directly.
+// residues"), so the selector works on r directly.  lut[S] spreads the 8 plane
+// bits of a lane to row order (LPL <= 4).
 template <int LPL>
-__device__ __forceinline__ u32 leading_zero_rows(const u32 r[4], u32 g)
+__device__ __forceinline__ u32 leading_zero_rows(const u32 r[4], u32 g, const u32 *lut)
 {
   const u32 S = fold8(r[0] | r[1] | r[2] | r[3]);
-  const u32 O = Grp<LPL>::red_or(S);
-  const u32 p_star = (u32)__clz((int)O) - 24u;          // first non-zero plane (0 = MSB); 8 if O == 0
-  const u32 has = (S << p_star) & 0x80u;
-  const u32 g_star = Grp<LPL>::red_min(has ? g : (u32)LPL);
-  return O ? LPL * p_star + g_star : 8u * LPL;
-}
-
-template <int LPL, int KIND>
-__device__ __forceinline__ void eval_module(const LineCtx<LPL> &c, const MpcFastModule &fm, const WinTab &wt,
-                                            u32 *shuf_line, int q, Best &best)
-{
-  u32 r[4], root_r;
-  module_residue<LPL, KIND>(c, fm, wt, shuf_line, r, root_r);
-  const u32 z = leading_zero_rows<LPL>(r, c.g);
-  if (best.z <= z) {     // ties go to the later module (VPC.cpp:389)
-    best.z = z;
-    best.q = q;
-    best.root_r = root_r;
-    best.cx = (u32)fm.cx;
-#pragma unroll
-    for (int e = 0; e < 4; e++) best.r[e] = r[e];
+  if constexpr (LPL <= 4) {
+    const u32 F = Grp<LPL>::red_or(lut[S] >> g);   // bit 31-row set <=> row non-zero
+    return (u32)__clz((int)F);                      // 32 when every row is zero ...
+  } else {
+    const u32 O = Grp<LPL>::red_or(S);
+    const u32 p_star = (u32)__clz((int)O) - 24u;          // first non-zero plane (0 = MSB); 8 if O == 0
+    const u32 has = (S << p_star) & 0x80u;
+    const u32 g_star = Grp<LPL>::red_min(has ? g : (u32)LPL);
+    return O ? LPL * p_star + g_star : 8u * LPL;
   }
-}
-
-template <int LPL, int Q>
-__device__ __forceinline__ void eval_all(const LineCtx<LPL> &, const MpcVpcParams &, const WinTab *, u32 *, Best &) {}
-
-template <int LPL, int Q, int KIND, int... REST>
-__device__ __forceinline__ void eval_all(const LineCtx<LPL> &c, const MpcVpcParams &P, const WinTab *wt,
-                                         u32 *shuf_line, Best &best)
-{
-  eval_module<LPL, KIND>(c, P.fm[Q], wt[Q], shuf_line, Q, best);
-  eval_all<LPL, Q + 1, REST...>(c, P, wt, shuf_line, best);
 }
 
 __device__ __forceinline__ void load_wintab(const u32 *tab, const MpcFastModule &fm, int W, u32 g, WinTab &wt)
@@ -227,6 +228,67 @@ __device__ __forceinline__ void load_wintab(const u32 *tab, const MpcFastModule 
     wt.sel[e] = t[4 * g + e];
     wt.c1[e] = t[W + 4 * g + e];
     wt.c2[e] = t[2 * W + 4 * g + e];
+  }
+}
+
+// per-kernel constant state of the compile-time module sequence
+template <int NPT>
+struct SeqTabs {
+  WinTab wt[NPT > 0 ? NPT : 1];
+  WinTab0 w0[NPT > 0 ? NPT : 1];
+};
+
+struct Winner {
+  u32 r[4];
+  u32 z;       // run-time sequence only
+  int q;
+  u32 root_r;
+  u32 cx;
+};
+
+// ---- compile-time sequence: evaluate every module, keep residues, select at the end ----
+template <int LPL, int NPT, int Q>
+__device__ __forceinline__ void eval_seq(const LineCtx<LPL> &, const MpcVpcParams &, const SeqTabs<NPT> &, u32 *,
+                                         const u32 *, const Pre4 &, u64, u32 (*)[4], u32 *, u32 *) {}
+
+template <int LPL, int NPT, int Q, int KIND, int... REST>
+__device__ __forceinline__ void eval_seq(const LineCtx<LPL> &c, const MpcVpcParams &P, const SeqTabs<NPT> &tabs,
+                                         u32 *shuf_line, const u32 *lut, const Pre4 &pre, u64 need_lines,
+                                         u32 (*R)[4], u32 *key, u32 *rootr)
+{
+  bool full = true;
+  if constexpr (LPL == 4 && Q + 1 < NPT) {
+    // prefilter: skip the module when no line of the wave can have a leading zero row
+    const u32 msb = row0_msbs<KIND>(c, pre, P.fm[Q], tabs.w0[Q]);
+    u64 b = __ballot(msb != 0);
+    b |= b >> 1;
+    b |= b >> 2;                                   // bit 4k: some lane of line k has an MSB set
+    full = (b & need_lines) != need_lines;         // wave-uniform
+  }
+  R[Q][0] = R[Q][1] = R[Q][2] = R[Q][3] = 0;
+  rootr[Q] = 0;
+  key[Q] = (u32)Q;                                  // z = 0
+  if (full) {
+    module_residue<LPL, KIND>(c, P.fm[Q], tabs.wt[Q], shuf_line, R[Q], rootr[Q]);
+    key[Q] = (leading_zero_rows<LPL>(R[Q], c.g, lut) << 4) | (u32)Q;
+  }
+  eval_seq<LPL, NPT, Q + 1, REST...>(c, P, tabs, shuf_line, lut, pre, need_lines, R, key, rootr);
+}
+
+template <int LPL, int KIND>
+__device__ __forceinline__ void eval_update(const LineCtx<LPL> &c, const MpcFastModule &fm, const WinTab &wt,
+                                            u32 *shuf_line, const u32 *lut, int q, Winner &best)
+{
+  u32 r[4], root_r;
+  module_residue<LPL, KIND>(c, fm, wt, shuf_line, r, root_r);
+  const u32 z = leading_zero_rows<LPL>(r, c.g, lut);
+  if (best.z <= z) {     // ties go to the later module (VPC.cpp:389)
+    best.z = z;
+    best.q = q;
+    best.root_r = root_r;
+    best.cx = (u32)fm.cx;
+#pragma unroll
+    for (int e = 0; e < 4; e++) best.r[e] = r[e];
   }
 }
 
@@ -249,53 +311,74 @@ __device__ __forceinline__ void run_flush(const RunStats &rs, const WgStats &st,
   }
 }
 
+// n_chunks = n_lines * LPL must be below 2^31 (the host splits larger batches)
 template <int LPL, int... KINDS>
 __global__ void __launch_bounds__(256)
-vpc_fast_kernel(const uint4 *__restrict__ lines, u64 n_lines, MpcVpcParams P,
+vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, MpcVpcParams P,
                 uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int L = 16 * LPL;
-  constexpr int W = L / 4;             // words per line
+  constexpr int W = L / 4;              // words per line
   constexpr int NPT = sizeof...(KINDS); // 0: module sequence known only at run time
   constexpr int kinds[NPT > 0 ? NPT : 1] = {KINDS...};
   const int K = P.M + 1, bins = P.hist_bins;
   WgStats st;
   st.sums = reinterpret_cast<u64 *>(smem);
   st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * K * 8 + 15) / 16));
-  // per-wave scratch for the byte-plane shuffle when LPL != 4: 64 lanes x 16 B
-  u32 *shuf = reinterpret_cast<u32 *>(smem + vpc_stats_smem(K, bins)) + (threadIdx.x >> 6) * 256;
-  stats_init(st, K, bins);
+  // row-order spread table for leading_zero_rows, then per-wave scratch for the
+  // byte-plane shuffle when LPL != 4 (64 lanes x 16 B)
+  u32 *lut = reinterpret_cast<u32 *>(smem + vpc_stats_smem(K, bins));
+  u32 *shuf = lut + 256 + (threadIdx.x >> 6) * 256;
+  {
+    // bit j of S (plane 7-j) -> row LPL*(7-j) of lane 0, i.e. bit 31 - LPL*(7-j)
+    u32 v = 0;
+    for (int j = 0; j < 8; j++)
+      if (threadIdx.x & (1u << j)) v |= 1u << ((31 - LPL * (7 - j)) & 31);
+    lut[threadIdx.x & 255] = v;
+  }
+  stats_init(st, K, bins);   // ends with __syncthreads()
 
   const u32 lane = threadIdx.x & 63;
   const u32 g = lane & (LPL - 1);      // column group inside the line
   u32 *shuf_line = shuf + (lane / LPL) * W;
-  const u64 n_chunks = n_lines * LPL;
-  const u64 stride = (u64)gridDim.x * blockDim.x;
   const u32 colmask0 = (g == 0) ? 0xffffff00u : 0xffffffffu;   // column 0 is exempt from the XOR stage
   const u32 uncomp = 8u * L;
   const int n_pred = NPT > 0 ? NPT : P.n_pred;
   const u32 enc_zero = (u32)P.enc_bits[1], enc_same = 32u + (u32)P.enc_bits[2], enc_unc = (u32)P.enc_bits[0];
+  const u32 cert_min = (u32)P.cert_min17;
 
   // loop-invariant predictor tables in registers (compile-time sequence only)
-  WinTab wt[NPT > 0 ? NPT : 1];
+  SeqTabs<NPT> tabs;
   if constexpr (NPT > 0) {
 #pragma unroll
-    for (int q = 0; q < NPT; q++)
-      if (kinds[q] == MPC_FK_DIFF || kinds[q] == MPC_FK_WEIGHT) load_wintab(P.tab, P.fm[q], W, g, wt[q]);
+    for (int q = 0; q < NPT; q++) {
+      if (kinds[q] == MPC_FK_DIFF || kinds[q] == MPC_FK_WEIGHT) {
+        load_wintab(P.tab, P.fm[q], W, g, tabs.wt[q]);
+        const u32 *t = P.tab + P.fm[q].tab_off;     // column group 0, word g (row-0 prefilter)
+        tabs.w0[q].sel = t[g & 3];
+        tabs.w0[q].c1 = t[W + (g & 3)];
+        tabs.w0[q].c2 = t[2 * W + (g & 3)];
+      }
+    }
   }
 
   RunStats rs = {0xffffffffu, 0, 0, 0};
 
-  u64 chunk0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+  // wave-uniform chunk index: the address math stays on the scalar unit
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 stride = gridDim.x * 256u;
+  u32 chunk0 = (blockIdx.x * 4u + wave) * 64u;
   uint4 vnext = make_uint4(0, 0, 0, 0);
-  if (chunk0 + lane < n_chunks) vnext = lines[chunk0 + lane];
+  if (chunk0 < n_chunks) vnext = lines[min(chunk0 + lane, n_chunks - 1u)];
   for (; chunk0 < n_chunks; chunk0 += stride) {
-    const u64 chunk = chunk0 + lane;
-    const bool valid = chunk < n_chunks;     // uniform inside a line group
+    const bool valid = lane < n_chunks - chunk0;     // uniform inside a line group
     const uint4 v = vnext;
-    vnext = make_uint4(0, 0, 0, 0);
-    if (chunk + stride < n_chunks) vnext = lines[chunk + stride];   // prefetch the next iteration
+    {   // prefetch the next iteration (clamped: a partial or missing next wave re-reads valid data)
+      const u32 nbase = chunk0 + stride;
+      if (nbase + 64u <= n_chunks) vnext = lines[nbase + lane];
+      else if (nbase < n_chunks) vnext = lines[min(nbase + lane, n_chunks - 1u)];
+    }
 
     LineCtx<LPL> c;
     c.x[0] = v.x; c.x[1] = v.y; c.x[2] = v.z; c.x[3] = v.w;
@@ -315,29 +398,64 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u64 n_lines, MpcVpcParams P,
     // Skip the prediction modules only when no line of the wave needs them
     // (wave-uniform branch; DPP needs every lane of a line group active).
     const bool need = valid && !is_zero && !is_same;
-    if (__any(need)) {
+    const u64 need_mask = __ballot(need);
+    if (need_mask) {
       c.b0 = c.w0 & 0xffu;
       c.rootb = c.b0 * 0x01010101u;
       c.xm1 = Grp<LPL>::prev(c.x[3]);
-      Best best;
-      best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
-      best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
+      Winner best;
       if constexpr (NPT > 0) {
-        eval_all<LPL, 0, KINDS...>(c, P, wt, shuf_line, best);
+        Pre4 pre = {0, 0, 0, 0};
+        if constexpr (LPL == 4 && NPT > 1) {
+          // word g of column group 0, and its predecessor
+          const u32 a0 = dpp<QP(0, 0, 0, 0)>(c.x[0]), a1 = dpp<QP(0, 0, 0, 0)>(c.x[1]);
+          const u32 a2 = dpp<QP(0, 0, 0, 0)>(c.x[2]), a3 = dpp<QP(0, 0, 0, 0)>(c.x[3]);
+          pre.y = (g & 2) ? ((g & 1) ? a3 : a2) : ((g & 1) ? a1 : a0);
+          pre.yprev = (g & 2) ? ((g & 1) ? a2 : a1) : a0;
+          bool any_consec = false;
+#pragma unroll
+          for (int q = 0; q + 1 < NPT; q++) any_consec = any_consec || (kinds[q] == MPC_FK_CONSEC);
+          if (any_consec) {
+            const u32 hi01 = perm(c.x[1], c.x[0], 0x07030602u), hi23 = perm(c.x[3], c.x[2], 0x07030602u);
+            pre.t3 = perm(hi23, hi01, 0x07060302u);
+            pre.t3prev = Grp<4>::prev(pre.t3);
+          }
+        }
+        u32 R[NPT][4], key[NPT], rootr[NPT];
+        eval_seq<LPL, NPT, 0, KINDS...>(c, P, tabs, shuf_line, lut, pre, need_mask & 0x1111111111111111ull, R, key,
+                                        rootr);
+        u32 bk = key[0];
+#pragma unroll
+        for (int q = 1; q < NPT; q++) bk = max(bk, key[q]);
+        best.q = (int)(bk & 15u);
+        best.cx = (u32)P.fm[0].cx;
+        best.root_r = rootr[0];
+#pragma unroll
+        for (int e = 0; e < 4; e++) best.r[e] = R[0][e];
+#pragma unroll
+        for (int q = 1; q < NPT; q++) {
+          const bool is = best.q == q;
+          best.cx = is ? (u32)P.fm[q].cx : best.cx;
+          best.root_r = is ? rootr[q] : best.root_r;
+#pragma unroll
+          for (int e = 0; e < 4; e++) best.r[e] = is ? R[q][e] : best.r[e];
+        }
       } else {
+        best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
+        best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
         for (int q = 0; q < n_pred; q++) {
           const MpcFastModule fm = P.fm[q];
           WinTab w;
           switch (fm.kind) {
-          case MPC_FK_ONEBASE: eval_module<LPL, MPC_FK_ONEBASE>(c, fm, w, shuf_line, q, best); break;
-          case MPC_FK_CONSEC: eval_module<LPL, MPC_FK_CONSEC>(c, fm, w, shuf_line, q, best); break;
-          case MPC_FK_DIFF: load_wintab(P.tab, fm, W, g, w); eval_module<LPL, MPC_FK_DIFF>(c, fm, w, shuf_line, q, best); break;
-          default: load_wintab(P.tab, fm, W, g, w); eval_module<LPL, MPC_FK_WEIGHT>(c, fm, w, shuf_line, q, best); break;
+          case MPC_FK_ONEBASE: eval_update<LPL, MPC_FK_ONEBASE>(c, fm, w, shuf_line, lut, q, best); break;
+          case MPC_FK_CONSEC: eval_update<LPL, MPC_FK_CONSEC>(c, fm, w, shuf_line, lut, q, best); break;
+          case MPC_FK_DIFF: load_wintab(P.tab, fm, W, g, w); eval_update<LPL, MPC_FK_DIFF>(c, fm, w, shuf_line, lut, q, best); break;
+          default: load_wintab(P.tab, fm, W, g, w); eval_update<LPL, MPC_FK_WEIGHT>(c, fm, w, shuf_line, lut, q, best); break;
           }
         }
       }
 
-      u32 enc = 0;
+      u32 enc = uncomp;
       if (n_pred > 0) {
         // XOR stage of the winner, on bytes
         u32 t[4];
@@ -347,16 +465,25 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u64 n_lines, MpcVpcParams P,
           const u32 f = best.cx ? ((best.r[e] >> 1) & L7F) : ((m << 7) - m);   // b>>1, or 0x7f where the MSB is set
           t[e] = best.r[e] ^ (e == 0 ? (f & colmask0) : f);
         }
-        u32 Z;
-        u32 bits = encode_rows(t, Z);
-        // zero-row runs in row order r = plane * LPL + g: 4 bits per run, 7 if longer than one row
-        const u32 Zprev_lane = Grp<LPL>::prev(Z), Zlast = Grp<LPL>::last(Z);
-        const u32 Znext_lane = Grp<LPL>::next(Z), Zfirst = Grp<LPL>::first(Z);
-        const u32 prevZ = (g == 0) ? (Zlast >> 1) : Zprev_lane;
-        const u32 nextZ = (g == LPL - 1) ? ((Zfirst << 1) & 0xffu) : Znext_lane;
-        const u32 starts = Z & ~prevZ;
-        bits += 4u * __popc(starts) + 3u * __popc(starts & nextZ);
-        enc = Grp<LPL>::red_add(bits);
+        // Incompressibility certificate: a row whose two 8-column halves are both non-zero
+        // and that has a bit outside columns 7/8 costs 17 bits (it is neither a single one
+        // nor an adjacent pair).  With cert_min17 such rows the line cannot beat 8*L bits.
+        const u32 Sf = fold8(t[0] | t[1]), Sb = fold8(t[2] | t[3]);
+        const u32 So = fold8(t[0] | (t[1] & 0x00ffffffu) | (t[2] & 0xffffff00u) | t[3]);
+        const u32 n17 = Grp<LPL>::red_add((u32)__popc(Sf & Sb & So));
+        const bool open = need && (n17 < cert_min);
+        if (__any(open)) {
+          u32 Z;
+          u32 bits = encode_rows(t, Z);
+          // zero-row runs in row order r = plane * LPL + g: 4 bits per run, 7 if longer than one row
+          const u32 Zprev_lane = Grp<LPL>::prev(Z), Zlast = Grp<LPL>::last(Z);
+          const u32 Znext_lane = Grp<LPL>::next(Z), Zfirst = Grp<LPL>::first(Z);
+          const u32 prevZ = (g == 0) ? (Zlast >> 1) : Zprev_lane;
+          const u32 nextZ = (g == LPL - 1) ? ((Zfirst << 1) & 0xffu) : Znext_lane;
+          const u32 starts = Z & ~prevZ;
+          bits += 4u * __popc(starts) + 3u * __popc(starts & nextZ);
+          enc = Grp<LPL>::red_add(bits);
+        }
       }
       // residues over all positions: the winner's (root position holds best.root_r, not
       // the raw root), or the raw bytes when the line stays uncompressed
@@ -385,7 +512,7 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u64 n_lines, MpcVpcParams P,
 
     // ---- per-line results: one lane per line ----
     if (valid && g == 0) {
-      const u64 line = chunk / LPL;
+      const u64 line = first_line + (chunk0 + lane) / LPL;
       if (sizes_out) sizes_out[line] = (uint16_t)size;
       if (sel_out) sel_out[line] = (int8_t)chosen;
       const u32 key = ((u32)(chosen + 1) << 16) | size;
@@ -425,33 +552,46 @@ static bool seq_matches(const MpcVpcParams *P)
 }
 
 template <int... KINDS>
-static hipError_t launch_seq(const uint4 *l, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes, int8_t *d_sel,
-                             u64 *d_stats, int grid, size_t smem, hipStream_t stream)
+static hipError_t launch_seq(const uint4 *l, u32 n_chunks, u64 first_line, const MpcVpcParams *P, uint16_t *d_sizes,
+                             int8_t *d_sel, u64 *d_stats, int grid, size_t smem, hipStream_t stream)
 {
   switch (P->L) {
-  case 32: hipLaunchKernelGGL((vpc_fast_kernel<2, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines, *P, d_sizes, d_sel, d_stats); break;
-  case 64: hipLaunchKernelGGL((vpc_fast_kernel<4, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines, *P, d_sizes, d_sel, d_stats); break;
-  case 128: hipLaunchKernelGGL((vpc_fast_kernel<8, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines, *P, d_sizes, d_sel, d_stats); break;
+  case 32: hipLaunchKernelGGL((vpc_fast_kernel<2, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_chunks, first_line, *P, d_sizes, d_sel, d_stats); break;
+  case 64: hipLaunchKernelGGL((vpc_fast_kernel<4, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_chunks, first_line, *P, d_sizes, d_sel, d_stats); break;
+  case 128: hipLaunchKernelGGL((vpc_fast_kernel<8, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_chunks, first_line, *P, d_sizes, d_sel, d_stats); break;
   default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-extern "C" size_t mpc_vpc_fast_smem(const MpcVpcParams *P) { return vpc_stats_smem(P->M + 1, P->hist_bins) + 4 * 1024; }
+// statistics + spread table (1 KiB) + shuffle scratch (4 waves x 1 KiB)
+extern "C" size_t mpc_vpc_fast_smem(const MpcVpcParams *P) { return vpc_stats_smem(P->M + 1, P->hist_bins) + 5 * 1024; }
 
 extern "C" hipError_t mpc_launch_vpc_fast(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
                                           int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
 {
   const size_t smem = mpc_vpc_fast_smem(P);
-  const uint4 *l = static_cast<const uint4 *>(d_lines);
-#define TRY_SEQ(...)                                                                                  \
-  if (seq_matches<__VA_ARGS__>(P)) return launch_seq<__VA_ARGS__>(l, n_lines, P, d_sizes, d_sel, d_stats, grid, smem, stream)
-  TRY_SEQ(OB, CS, DF, WT);   // the 4-predictor "probe" sequence
-  TRY_SEQ(OB, CS);
-  TRY_SEQ(OB);
-  TRY_SEQ(CS);
-  TRY_SEQ(DF);
-  TRY_SEQ(WT);
+  const u32 LPL = (u32)P->L / 16u;
+  // 32-bit chunk indices inside the kernel: at most 2^30 chunks (16 GiB) per launch
+  const u64 max_lines = (1ull << 30) / LPL;
+  for (u64 done = 0; done < n_lines; done += max_lines) {
+    const u64 take = (n_lines - done) < max_lines ? (n_lines - done) : max_lines;
+    const uint4 *l = static_cast<const uint4 *>(d_lines) + done * LPL;
+    const u32 n_chunks = (u32)(take * LPL);
+    hipError_t e;
+#define TRY_SEQ(...)                                                                                   \
+    if (seq_matches<__VA_ARGS__>(P))                                                                   \
+      e = launch_seq<__VA_ARGS__>(l, n_chunks, done, P, d_sizes, d_sel, d_stats, grid, smem, stream);  \
+    else
+    TRY_SEQ(OB, CS, DF, WT)   // the 4-predictor "probe" sequence
+    TRY_SEQ(OB, CS)
+    TRY_SEQ(OB)
+    TRY_SEQ(CS)
+    TRY_SEQ(DF)
+    TRY_SEQ(WT)
+      e = launch_seq<>(l, n_chunks, done, P, d_sizes, d_sel, d_stats, grid, smem, stream);   // run-time sequence
 #undef TRY_SEQ
-  return launch_seq<>(l, n_lines, P, d_sizes, d_sel, d_stats, grid, smem, stream);   // run-time sequence
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }

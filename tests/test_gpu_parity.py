@@ -251,19 +251,27 @@ def test_device_resident_path_and_synth(mpc, oracle, configs, traces):
         assert (ev.stats_vector() == o.stats_vector()).all()
 
 
-def test_full_size_properties(mpc, configs):
-    """Size-independent checks at a BASELINE-scale buffer (no oracle run): counts
-    add up, random data is incompressible, sharding the buffer and merging the
-    statistics equals one pass, repeating a pass doubles every counter."""
+def test_full_size_properties(mpc, configs, golden_dir):
+    """Checks at a BASELINE-scale buffer: per-line outputs of 32 Mi random lines
+    against the oracle-made golden list of the lines that do compress; counts add
+    up; sharding the buffer and merging the statistics equals one pass; repeating
+    a pass doubles every counter."""
+    import json
+    import os
     import torch
     dev = torch.device("cuda:0")
     L, n = 64, 32 << 20                      # 2 GiB of lines
     buf = torch.empty(n * L, dtype=torch.uint8, device=dev)
     cfg = configs.probe_config(L)
+    with open(os.path.join(golden_dir, "random_u32_32Mi_exceptions.json")) as f:
+        gold = json.load(f)
+    assert gold["n_lines"] == n
     for kind in ("random_u32", "mixed"):
         mpc.synth_fill(buf.data_ptr(), n, L, kind)
         whole = mpc.VPC(cfg)
-        whole.compress_device(buf.data_ptr(), n)
+        d_s = torch.empty(n, dtype=torch.int16, device=dev)
+        d_c = torch.empty(n, dtype=torch.int8, device=dev)
+        whole.compress_device(buf.data_ptr(), n, d_s.data_ptr(), d_c.data_ptr())
         v = whole.stats_vector()
         assert v[0] == n and v[1] == n * 512
         K, B = 7, whole.hist_bins
@@ -271,8 +279,12 @@ def test_full_size_properties(mpc, configs):
         assert int(hist.sum()) == n
         sizes = np.arange(B, dtype=np.uint64)
         assert int((hist * sizes[None, :]).sum()) == int(v[2])
+        assert int(d_s.to(torch.int64).sum().item()) == int(v[2])
         if kind == "random_u32":
-            assert int(hist[0, 515]) == n        # every line uncompressed: 512 + 3 id bits
+            # every line is 512 + 3 id bits / cluster -1, except the oracle's golden exceptions
+            odd = torch.nonzero((d_s != gold["default_size"]) | (d_c != gold["default_cluster"])).flatten().cpu().numpy()
+            got = [{"line": int(i), "size": int(d_s[int(i)].item()), "cluster": int(d_c[int(i)].item())} for i in odd]
+            assert got == gold["exceptions"]
         # 3 unequal shards on separate handles, merged == whole
         parts = mpc.VPC(cfg)
         cuts = [0, n // 3 + 5, n // 2 + 77, n]
