@@ -246,33 +246,60 @@ struct Winner {
   u32 cx;
 };
 
-// ---- compile-time sequence: evaluate every module, keep residues, select at the end ----
+// ---- compile-time sequence: modules in order; a module that passes the wave-uniform
+// row-0 prefilter is skipped (it cannot win); the winner is updated with selects ----
+template <int LPL>
+__device__ __forceinline__ void take_if_better(Winner &best, const u32 r[4], u32 z, int q, u32 root_r, u32 cx)
+{
+  const bool take = best.z <= z;     // ties go to the later module (VPC.cpp:389)
+  best.z = take ? z : best.z;
+  best.q = take ? q : best.q;
+  best.root_r = take ? root_r : best.root_r;
+  best.cx = take ? cx : best.cx;
+#pragma unroll
+  for (int e = 0; e < 4; e++) best.r[e] = take ? r[e] : best.r[e];
+}
+
 template <int LPL, int NPT, int Q>
 __device__ __forceinline__ void eval_seq(const LineCtx<LPL> &, const MpcVpcParams &, const SeqTabs<NPT> &, u32 *,
-                                         const u32 *, const Pre4 &, u64, u32 (*)[4], u32 *, u32 *) {}
+                                         const u32 *, const Pre4 &, u64, Winner &, bool) {}
 
 template <int LPL, int NPT, int Q, int KIND, int... REST>
 __device__ __forceinline__ void eval_seq(const LineCtx<LPL> &c, const MpcVpcParams &P, const SeqTabs<NPT> &tabs,
                                          u32 *shuf_line, const u32 *lut, const Pre4 &pre, u64 need_lines,
-                                         u32 (*R)[4], u32 *key, u32 *rootr)
+                                         Winner &best, bool any_full)
 {
-  bool full = true;
-  if constexpr (LPL == 4 && Q + 1 < NPT) {
-    // prefilter: skip the module when no line of the wave can have a leading zero row
-    const u32 msb = row0_msbs<KIND>(c, pre, P.fm[Q], tabs.w0[Q]);
-    u64 b = __ballot(msb != 0);
-    b |= b >> 1;
-    b |= b >> 2;                                   // bit 4k: some lane of line k has an MSB set
-    full = (b & need_lines) != need_lines;         // wave-uniform
+  if constexpr (Q + 1 < NPT) {
+    bool full = true;
+    if constexpr (LPL == 4) {
+      // prefilter: skip the module when no line of the wave can have a leading zero row
+      const u32 msb = row0_msbs<KIND>(c, pre, P.fm[Q], tabs.w0[Q]);
+      u64 b = __ballot(msb != 0);
+      b |= b >> 1;
+      b |= b >> 2;                                   // bit 4k: some lane of line k has an MSB set
+      full = (b & need_lines) != need_lines;         // wave-uniform
+    }
+    if (full) {
+      u32 r[4], root_r;
+      module_residue<LPL, KIND>(c, P.fm[Q], tabs.wt[Q], shuf_line, r, root_r);
+      take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), Q, root_r, (u32)P.fm[Q].cx);
+      any_full = true;
+    }
+    eval_seq<LPL, NPT, Q + 1, REST...>(c, P, tabs, shuf_line, lut, pre, need_lines, best, any_full);
+  } else {
+    // the last module is always evaluated; its z only matters against an earlier candidate
+    u32 r[4], root_r;
+    module_residue<LPL, KIND>(c, P.fm[Q], tabs.wt[Q], shuf_line, r, root_r);
+    if (any_full) {
+      take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), Q, root_r, (u32)P.fm[Q].cx);
+    } else {
+      best.q = Q;
+      best.root_r = root_r;
+      best.cx = (u32)P.fm[Q].cx;
+#pragma unroll
+      for (int e = 0; e < 4; e++) best.r[e] = r[e];
+    }
   }
-  R[Q][0] = R[Q][1] = R[Q][2] = R[Q][3] = 0;
-  rootr[Q] = 0;
-  key[Q] = (u32)Q;                                  // z = 0
-  if (full) {
-    module_residue<LPL, KIND>(c, P.fm[Q], tabs.wt[Q], shuf_line, R[Q], rootr[Q]);
-    key[Q] = (leading_zero_rows<LPL>(R[Q], c.g, lut) << 4) | (u32)Q;
-  }
-  eval_seq<LPL, NPT, Q + 1, REST...>(c, P, tabs, shuf_line, lut, pre, need_lines, R, key, rootr);
 }
 
 template <int LPL, int KIND>
@@ -281,15 +308,7 @@ __device__ __forceinline__ void eval_update(const LineCtx<LPL> &c, const MpcFast
 {
   u32 r[4], root_r;
   module_residue<LPL, KIND>(c, fm, wt, shuf_line, r, root_r);
-  const u32 z = leading_zero_rows<LPL>(r, c.g, lut);
-  if (best.z <= z) {     // ties go to the later module (VPC.cpp:389)
-    best.z = z;
-    best.q = q;
-    best.root_r = root_r;
-    best.cx = (u32)fm.cx;
-#pragma unroll
-    for (int e = 0; e < 4; e++) best.r[e] = r[e];
-  }
+  take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), q, root_r, (u32)fm.cx);
 }
 
 // run-length statistics of one lane (only lane g == 0 of a line uses them)
@@ -374,11 +393,8 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
   for (; chunk0 < n_chunks; chunk0 += stride) {
     const bool valid = lane < n_chunks - chunk0;     // uniform inside a line group
     const uint4 v = vnext;
-    {   // prefetch the next iteration (clamped: a partial or missing next wave re-reads valid data)
-      const u32 nbase = chunk0 + stride;
-      if (nbase + 64u <= n_chunks) vnext = lines[nbase + lane];
-      else if (nbase < n_chunks) vnext = lines[min(nbase + lane, n_chunks - 1u)];
-    }
+    // prefetch the next iteration (clamped: past the end it re-reads the last chunk)
+    vnext = lines[min(chunk0 + stride + lane, n_chunks - 1u)];
 
     LineCtx<LPL> c;
     c.x[0] = v.x; c.x[1] = v.y; c.x[2] = v.z; c.x[3] = v.w;
@@ -401,7 +417,7 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
     const u64 need_mask = __ballot(need);
     if (need_mask) {
       c.b0 = c.w0 & 0xffu;
-      c.rootb = c.b0 * 0x01010101u;
+      c.rootb = perm(c.w0, c.w0, 0u);            // byte 0 replicated
       c.xm1 = Grp<LPL>::prev(c.x[3]);
       Winner best;
       if constexpr (NPT > 0) {
@@ -421,25 +437,10 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
             pre.t3prev = Grp<4>::prev(pre.t3);
           }
         }
-        u32 R[NPT][4], key[NPT], rootr[NPT];
-        eval_seq<LPL, NPT, 0, KINDS...>(c, P, tabs, shuf_line, lut, pre, need_mask & 0x1111111111111111ull, R, key,
-                                        rootr);
-        u32 bk = key[0];
-#pragma unroll
-        for (int q = 1; q < NPT; q++) bk = max(bk, key[q]);
-        best.q = (int)(bk & 15u);
-        best.cx = (u32)P.fm[0].cx;
-        best.root_r = rootr[0];
-#pragma unroll
-        for (int e = 0; e < 4; e++) best.r[e] = R[0][e];
-#pragma unroll
-        for (int q = 1; q < NPT; q++) {
-          const bool is = best.q == q;
-          best.cx = is ? (u32)P.fm[q].cx : best.cx;
-          best.root_r = is ? rootr[q] : best.root_r;
-#pragma unroll
-          for (int e = 0; e < 4; e++) best.r[e] = is ? R[q][e] : best.r[e];
-        }
+        best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
+        best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
+        eval_seq<LPL, NPT, 0, KINDS...>(c, P, tabs, shuf_line, lut, pre, need_mask & 0x1111111111111111ull, best,
+                                        false);
       } else {
         best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
         best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
@@ -457,13 +458,23 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
 
       u32 enc = uncomp;
       if (n_pred > 0) {
-        // XOR stage of the winner, on bytes
+        // XOR stage of the winner, on bytes: b ^ (b >> 1), or b ^ 0x7f where the MSB is set;
+        // column 0 untouched.  The flavour is usually the same for the whole wave.
         u32 t[4];
+        const u64 cx_mask = __ballot(best.cx != 0);
+        if ((cx_mask & need_mask) == need_mask) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const u32 m = (best.r[e] >> 7) & 0x01010101u;
-          const u32 f = best.cx ? ((best.r[e] >> 1) & L7F) : ((m << 7) - m);   // b>>1, or 0x7f where the MSB is set
-          t[e] = best.r[e] ^ (e == 0 ? (f & colmask0) : f);
+          for (int e = 0; e < 4; e++) {
+            const u32 f = (best.r[e] >> 1) & L7F;
+            t[e] = best.r[e] ^ (e == 0 ? (f & colmask0) : f);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const u32 m = (best.r[e] >> 7) & 0x01010101u;
+            const u32 f = best.cx ? ((best.r[e] >> 1) & L7F) : ((m << 7) - m);
+            t[e] = best.r[e] ^ (e == 0 ? (f & colmask0) : f);
+          }
         }
         // Incompressibility certificate: a row whose two 8-column halves are both non-zero
         // and that has a bit outside columns 7/8 costs 17 bits (it is neither a single one
