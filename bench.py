@@ -106,6 +106,7 @@ def main():
     mpc = importlib.import_module(PKG)
     configs = importlib.import_module(f"{PKG}.configs")
     traces = importlib.import_module(f"{PKG}.traces")
+    sharded = importlib.import_module(f"{PKG}.sharded")
 
     kind, L = WORKLOADS[args.workload]
     n = args.lines
@@ -130,9 +131,7 @@ def main():
             ev_pair[1].record(stream)
         if world > 1:
             # the path's only exchange: sum all-reduce of the integer statistics vector
-            v = torch.from_numpy(ev.stats_vector().view(np.int64)).to(dev)
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
-            return v
+            return sharded.all_reduce_stats(ev.stats_vector(), dev)
         return None
 
     for _ in range(args.warmup):

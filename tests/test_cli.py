@@ -1,0 +1,184 @@
+"""The `compressor` CLI and `bin/run` driver: flag handling and error behaviour on
+CPU; on the GPU box, byte-for-byte CSV / stdout text against the formats of the
+reference (src/main.cpp:129-165, VPC.h:78-211, BDI.h:35-84, CompResult.h:37-74)
+filled from the oracle's statistics."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pkg
+
+BIN = os.path.join(ROOT, "bin")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    pkg("build").build_all()
+    assert os.path.exists(os.path.join(BIN, "compressor"))
+    return os.path.join(BIN, "compressor")
+
+
+def run(cmd, cwd=BIN):
+    return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def fmt_double(x: float) -> str:
+    """{fmt}'s "{}" of a double: shortest round-trip, no trailing ".0"."""
+    if x != x:
+        return "nan"
+    if x in (float("inf"), float("-inf")):
+        return "inf" if x > 0 else "-inf"
+    r = repr(float(x))
+    if "e" in r:
+        m, e = r.split("e")
+        if m.endswith(".0"):
+            m = m[:-2]
+        return m + "e" + e
+    return r[:-2] if r.endswith(".0") else r
+
+
+def test_fmt_double_helper():
+    assert fmt_double(170.66666666666666) == "170.66666666666666"
+    assert fmt_double(3.0) == "3" and fmt_double(0.0) == "0"
+    assert fmt_double(0.9941747572815534) == "0.9941747572815534"
+    assert fmt_double(1e-05) == "1e-05" and fmt_double(2.5e-07) == "2.5e-07"
+
+
+def test_help_and_missing_arguments(cli):
+    r = run([cli, "-h"])
+    assert r.returncode == 0 and "-a, --algorithm arg" in r.stdout and "Default=VPC" in r.stdout
+    # no input -> help, exit 0; VPC without -c -> help, exit 0 (reference main.cpp:52-66)
+    assert run([cli]).returncode == 0
+    r = run([cli, "-a", "VPC", "-i", "x/y.npy"])
+    assert r.returncode == 0 and "Usage:" in r.stdout
+
+
+def test_out_of_scope_algorithms_and_formats(cli, traces, tmp_path):
+    d = tmp_path / "ds"
+    d.mkdir()
+    p = traces.save_npy(str(d / "t.npy"), traces.zeros(8, 64))
+    for algo in ("FPC", "BPC", "CPACK", "SC2", "PATTERN", "VIEWER"):
+        r = run([cli, "-a", algo, "-i", p, "-o", str(tmp_path)])
+        assert r.returncode == 1 and "not part of this build" in r.stdout
+    r = run([cli, "-a", "BDI", "-i", str(d / "t.log"), "-o", str(tmp_path)])
+    assert r.returncode == 1 and "not part of this build" in r.stdout
+    r = run([cli, "-a", "BDI", "-i", str(d / "t.bin"), "-o", str(tmp_path)])
+    assert r.returncode != 0 and "Unsupported extension" in r.stderr
+
+
+def test_bad_config_messages(cli, traces, tmp_path):
+    import torch
+    d = tmp_path / "ds"
+    d.mkdir()
+    p = traces.save_npy(str(d / "t.npy"), traces.zeros(8, 64))
+    r = run([cli, "-a", "VPC", "-i", p, "-c", str(tmp_path / "missing.json"), "-o", str(tmp_path)])
+    assert r.returncode == 1 and "is not valid path." in r.stdout
+    bad = tmp_path / "bad.json"
+    bad.write_text("{ nope")
+    r = run([cli, "-a", "VPC", "-i", p, "-c", str(bad), "-o", str(tmp_path)])
+    assert r.returncode == 1 and "is not valid json file." in r.stdout
+    if not torch.cuda.is_available():
+        # no GPU: the product refuses loudly instead of falling back to a CPU path
+        r = run([cli, "-a", "BDI", "-i", p, "-o", str(tmp_path)])
+        assert r.returncode == 1 and "no CPU fallback" in r.stdout
+
+
+# ---------------------------------------------------------------------------------
+def vpc_expected_rows(o, workload):
+    st, M = o.st, o.M
+    row = f"{workload},{st.original_bits},{st.compressed_bits},{fmt_double(st.comp_ratio)},"
+    for k in range(M + 1):
+        row += f"{st.c_original_bits[k]},{st.c_compressed_bits[k]},{fmt_double(st.c_comp_ratio[k])},"
+    det = f"{workload},"
+    for k in range(M + 1):
+        det += f"{fmt_double(st.mae[k])},{fmt_double(st.mse[k])},"
+    h = o.hist()
+    for k in range(1, M + 1):
+        det += "".join(f"{int(h[k][s])}," for s in range(288))
+    return row, det
+
+
+def vpc_headers(M):
+    h1 = "workload,total,,," + "".join(f"{i},,," for i in range(-1, M)) + "\n"
+    h1 += ",original_size,compressed_size,compression_ratio,count," + "original_size,compressed_size,compression_ratio," * (M + 1) + "\n"
+    h2 = "workload," + "".join(f"{i},," for i in range(-1, M)) + "".join(f"{i}," + "," * 287 for i in range(M)) + "\n"
+    h2 += "," + "mae,mse," * (M + 1) + "".join(f"{j}," for j in range(288)) * M + "\n"
+    return h1, h2
+
+
+@pytest.mark.gpu
+def test_bin_run_vpc_dataset(cli, oracle, configs, traces, tmp_path):
+    """bin/run over a dataset directory: split/<x>set.npy -> out/split/, top-level
+    .npy -> out/.  Includes BASELINE config 1 (1M all-zero lines -> 999 999 lines
+    processed, ratio 170.66666666666666)."""
+    ds, out = tmp_path / "data", tmp_path / "out"
+    (ds / "splitA").mkdir(parents=True)
+    (out / "splitA").mkdir(parents=True)
+    cfg = configs.probe_config(64)
+    cfg_path = configs.write_config(cfg, str(tmp_path / "probe64.json"))
+    zeros = traces.zeros(1_000_000, 64)
+    mix = np.concatenate([traces.structured(5000, 64), traces.mixed(3000, 64), traces.word_same(100, 64)])
+    traces.save_npy(str(ds / "splitA" / "zeros_testset.npy"), zeros)
+    traces.save_npy(str(ds / "splitA" / "mix_trainset.npy"), mix)
+    traces.save_npy(str(ds / "top.npy"), mix[:1001])
+    r = run([os.path.join(BIN, "run"), "VPC", str(ds), str(out), cfg_path])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().split("\n")
+    # echo lines + comp.ratio lines, in directory order
+    o = oracle.VpcOracle(cfg)
+    expect_stdout, sum_rows, det_rows = [], {"splitA": [], "": []}, {"splitA": [], "": []}
+    for split, name, data in (("splitA", "mix_trainset", mix), ("splitA", "zeros_testset", zeros), ("", "top", mix[:1001])):
+        o.reset()
+        o.compress(data[:-1])                       # the driver never sees the last row
+        # bin/run echoes "$split : name"; for top-level files $split is whatever the
+        # directory walk left behind (the last entry: "top.npy"), as in the reference
+        label = ("splitA : " if split else "top.npy : ") + name
+        expect_stdout += [label, "comp.ratio: " + fmt_double(o.st.comp_ratio)]
+        parent = "splitA" if split else "data"
+        row, det = vpc_expected_rows(o, f"{parent}_{name}")
+        sum_rows[split].append(row)
+        det_rows[split].append(det)
+        if name == "zeros_testset":
+            assert o.st.lines == 999_999 and fmt_double(o.st.comp_ratio) == "170.66666666666666"
+    assert lines == expect_stdout
+    h1, h2 = vpc_headers(6)
+    for split in ("splitA", ""):
+        d = out / split if split else out
+        assert (d / "probe64_results.csv").read_text() == h1 + "".join(r_ + "\n" for r_ in sum_rows[split])
+        assert (d / "probe64_results_detail.csv").read_text() == h2 + "".join(r_ + "\n" for r_ in det_rows[split])
+    # a second run appends rows without repeating the header
+    r = run([os.path.join(BIN, "run"), "VPC", str(ds), str(out), cfg_path])
+    assert r.returncode == 0
+    assert (out / "probe64_results.csv").read_text() == h1 + (sum_rows[""][0] + "\n") * 2
+
+
+@pytest.mark.gpu
+def test_cli_bdi(cli, oracle, traces, tmp_path):
+    ds = tmp_path / "bench"
+    ds.mkdir()
+    data = np.concatenate([traces.bdi_stress(2800, 128), traces.pointers_u64(1000, 128)])
+    p = traces.save_npy(str(ds / "ptr.npy"), data)
+    r = run([cli, "-a", "BDI", "-i", p, "-o", str(tmp_path)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    o = oracle.BdiOracle(128)
+    o.compress(data[:-1])
+    assert r.stdout.strip().split("\n")[-1] == "comp.ratio: " + fmt_double(o.st.comp_ratio)
+    hdr = ("Workload,Original Size,Compressed Size,Compression Ratio,Zeros,Repeated,B8D1,B8D2,B8D4,B4D1,B4D2,B2D1,"
+           "Uncompressed,\n")
+    row = f"bench_ptr,{o.st.original_bits},{o.st.compressed_bits},{fmt_double(o.st.comp_ratio)}," + \
+        "".join(f"{o.st.counts[i]}," for i in range(9)) + "\n"
+    assert (tmp_path / "BDI_results.csv").read_text() == hdr + row
+    assert not (tmp_path / "BDI_results_detail.csv").exists()
+
+
+@pytest.mark.gpu
+def test_cli_line_size_mismatch_is_an_error(cli, configs, traces, tmp_path):
+    d = tmp_path / "ds"
+    d.mkdir()
+    p = traces.save_npy(str(d / "t.npy"), traces.random_u32(10, 32))
+    cfg_path = configs.write_config(configs.probe_config(64), str(tmp_path / "c.json"))
+    r = run([cli, "-a", "VPC", "-i", p, "-c", cfg_path, "-o", str(tmp_path)])
+    assert r.returncode == 1 and "32-byte lines" in r.stdout

@@ -297,3 +297,43 @@ def test_full_size_properties(mpc, configs, golden_dir):
         whole.compress_device(buf.data_ptr(), n)
         assert (whole.stats_vector() == 2 * v).all()
         whole.close(); parts.close()
+
+
+def _gpu_shard_worker(rank, world, port, npy_path, out_dir):
+    import importlib
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
+    mpc = importlib.import_module("cal_22-mpc_amd")
+    sharded = importlib.import_module("cal_22-mpc_amd.sharded")
+    configs = importlib.import_module("cal_22-mpc_amd.configs")
+    ev = mpc.VPC(configs.probe_config(64), device=0)
+    total = sharded.evaluate_sharded(ev, npy_path, rank, world)
+    assert (ev.stats_vector() == total).all()
+    np.save(os.path.join(out_dir, f"tot_{rank}.npy"), total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_npy(mpc, oracle, configs, traces, tmp_path):
+    """Two processes, each evaluating its contiguous half of one .npy trace on the
+    GPU, one all-reduce of the statistics vector: equals the oracle over the
+    whole trace (minus the reference's dropped last row)."""
+    import socket
+    import torch.multiprocessing as mp
+    lines = np.concatenate([traces.structured(30000, 64, seed=21), traces.mixed(20001, 64)])
+    p = traces.save_npy(str(tmp_path / "t.npy"), lines)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gpu_shard_worker, args=(2, port, p, str(tmp_path)), nprocs=2, join=True)
+    o = oracle.VpcOracle(configs.probe_config(64))
+    o.compress(lines[:-1])
+    for r in range(2):
+        assert (np.load(tmp_path / f"tot_{r}.npy") == o.stats_vector()).all()
