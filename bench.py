@@ -174,6 +174,14 @@ def main():
     probe_gbps = n * L / (min(probe_ms[1:]) / 1e3) / 1e9
 
     if rank == 0:
+        traffic = args.traffic_bytes
+        if traffic is None:
+            # HBM bytes per launch measured in a separate rocprofv3 --pmc pass of this exact workload
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    traffic = json.load(f).get(f"{args.algo}/{args.workload}/{L}/{n}", {}).get("bytes")
+            except OSError:
+                traffic = None
         achieved = n * L / avg_kern_s / 1e9     # algorithmic bytes: L read per block
         out = {
             "metric": "64B blocks/s (whole node) + achieved HBM GB/s fraction; ratio bit-exact vs CPU",
@@ -193,7 +201,7 @@ def main():
                        "algorithm": args.algo, "line_size": L, "blocks_per_gpu": n,
                        "sharding": f"contiguous x{world}", "compression_ratio": ratio},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": args.traffic_bytes,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "vpc_fast_kernel<4>" if (args.algo == "VPC" and L == 64) else args.algo,
                          "kernel_ms_avg": avg_kern_s * 1e3, "kernel_ms_min": min(kern_ms),
                          "algorithmic_bytes_per_launch": n * L,
