@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--lines", type=int, default=256 << 20, help="blocks per GPU (default 256 Mi = 16 GiB at 64 B)")
     ap.add_argument("--algo", default="VPC", choices=["VPC", "BDI"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-single-gpu", action="store_true",
+                    help="development: run the N>1 code path with every rank on cuda:0 and the gloo backend "
+                         "(a 1-GPU box cannot host an RCCL group); never used for reported numbers")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), copied into roofline.traffic")
     args = ap.parse_args()
@@ -98,10 +101,15 @@ def main():
         raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
+    if args.rehearse_single_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
+        if args.rehearse_single_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
 
     mpc = importlib.import_module(PKG)
     configs = importlib.import_module(f"{PKG}.configs")
@@ -131,7 +139,7 @@ def main():
             ev_pair[1].record(stream)
         if world > 1:
             # the path's only exchange: sum all-reduce of the integer statistics vector
-            return sharded.all_reduce_stats(ev.stats_vector(), dev)
+            return sharded.all_reduce_stats(ev.stats_vector(), None if args.rehearse_single_gpu else dev)
         return None
 
     for _ in range(args.warmup):
@@ -151,7 +159,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_single_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -160,6 +168,9 @@ def main():
     # sanity: every block of every step was counted exactly once
     v = ev.stats_vector()
     assert int(v[0]) == n * args.steps, (int(v[0]), n * args.steps)
+    if world > 1:
+        # the all-reduced vector of the last step counts every rank's blocks of every step
+        assert int(last[0]) == world * n * args.steps, (int(last[0]), world * n * args.steps)
     ratio = float(v[1]) / float(v[2])
 
     # measured streaming-read ceiling on the same buffer

@@ -21,7 +21,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmpc_hip.so")
+LIB_PATH = os.environ.get("MPC_HIP_LIB") or os.path.join(HERE, "libmpc_hip.so")   # override: development builds only
 
 MPC_PATH_VPC_FAST, MPC_PATH_VPC_GENERIC, MPC_PATH_BDI = 1, 2, 3
 SYNTH_KINDS = {"zeros": 0, "random_u32": 1, "sine_f32": 2, "mixed": 3, "pointers_u64": 4}

@@ -28,6 +28,10 @@
 // whose sequence has no instantiation run the same code with a runtime loop.
 #include "mpc_kernel_common.h"
 
+#ifndef MPC_ABLATE
+#define MPC_ABLATE 0   // development-only timing ablations (tools/ablate.sh); results are WRONG when non-zero
+#endif
+
 // ---------------------------------------------------------------------------
 // common encoder on this lane's 8 rows (bit j <-> plane 7-j).  t[4] = transformed
 // residue bytes of columns 16g..16g+15.  Returns the bits of the non-zero rows.
@@ -271,13 +275,15 @@ __device__ __forceinline__ void eval_seq(const LineCtx<LPL> &c, const MpcVpcPara
 {
   if constexpr (Q + 1 < NPT) {
     bool full = true;
-    if constexpr (LPL == 4) {
+    if constexpr (MPC_ABLATE & 8) full = false;
+    if constexpr (LPL == 4 && !(MPC_ABLATE & 8)) {
       // prefilter: skip the module when no line of the wave can have a leading zero row
       const u32 msb = row0_msbs<KIND>(c, pre, P.fm[Q], tabs.w0[Q]);
       u64 b = __ballot(msb != 0);
       b |= b >> 1;
       b |= b >> 2;                                   // bit 4k: some lane of line k has an MSB set
       full = (b & need_lines) != need_lines;         // wave-uniform
+      if constexpr (MPC_ABLATE & 8) full = false;
     }
     if (full) {
       u32 r[4], root_r;
@@ -289,7 +295,8 @@ __device__ __forceinline__ void eval_seq(const LineCtx<LPL> &c, const MpcVpcPara
   } else {
     // the last module is always evaluated; its z only matters against an earlier candidate
     u32 r[4], root_r;
-    module_residue<LPL, KIND>(c, P.fm[Q], tabs.wt[Q], shuf_line, r, root_r);
+    if constexpr (MPC_ABLATE & 4) { r[0] = c.x[0]; r[1] = c.x[1]; r[2] = c.x[2]; r[3] = c.x[3]; root_r = 0; }
+    else module_residue<LPL, KIND>(c, P.fm[Q], tabs.wt[Q], shuf_line, r, root_r);
     if (any_full) {
       take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), Q, root_r, (u32)P.fm[Q].cx);
     } else {
@@ -311,23 +318,39 @@ __device__ __forceinline__ void eval_update(const LineCtx<LPL> &c, const MpcFast
   take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), q, root_r, (u32)fm.cx);
 }
 
-// run-length statistics of one lane (only lane g == 0 of a line uses them)
+// Run-length statistics.  Every lane of a line sees the same (cluster, size) key; all
+// lanes accumulate the byte sums of their own 16 columns, the lead lane (g == 0) counts lines.
 struct RunStats {
   u32 key;     // (cluster + 1) << 16 | size
   u32 cnt;
   u32 acc_r, acc_r2;
 };
 
-__device__ __forceinline__ void run_flush(const RunStats &rs, const WgStats &st, int K, int bins)
+__device__ __forceinline__ void run_flush(const RunStats &rs, const WgStats &st, int K, int bins, bool lead)
 {
   if (rs.cnt) {
     const int k = (int)(rs.key >> 16);
-    atomicAdd(&st.hist[k * bins + (int)(rs.key & 0xffffu)], rs.cnt);
+    if (lead) atomicAdd(&st.hist[k * bins + (int)(rs.key & 0xffffu)], rs.cnt);
     if (rs.acc_r | rs.acc_r2) {
       atomicAdd(&st.sums[k], (u64)rs.acc_r);
       atomicAdd(&st.sums[K + k], (u64)rs.acc_r2);
     }
   }
+}
+
+// any lane of a line set -> every lane of that line set (scalar-unit work on a ballot)
+template <int LPL>
+__device__ __forceinline__ u64 line_any(u64 b)
+{
+  constexpr u64 lead = LPL == 2 ? 0x5555555555555555ull : (LPL == 4 ? 0x1111111111111111ull : 0x0101010101010101ull);
+  b |= b >> 1;
+  if (LPL >= 4) b |= b >> 2;
+  if (LPL >= 8) b |= b >> 4;
+  b &= lead;
+  b |= b << 1;
+  if (LPL >= 4) b |= b << 2;
+  if (LPL >= 8) b |= b << 4;
+  return b;
 }
 
 // n_chunks = n_lines * LPL must be below 2^31 (the host splits larger batches)
@@ -383,6 +406,7 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
   }
 
   RunStats rs = {0xffffffffu, 0, 0, 0};
+  u32 iter = 0;
 
   // wave-uniform chunk index: the address math stays on the scalar unit
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -391,7 +415,8 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
   uint4 vnext = make_uint4(0, 0, 0, 0);
   if (chunk0 < n_chunks) vnext = lines[min(chunk0 + lane, n_chunks - 1u)];
   for (; chunk0 < n_chunks; chunk0 += stride) {
-    const bool valid = lane < n_chunks - chunk0;     // uniform inside a line group
+    const u32 rem = n_chunks - chunk0;                                   // wave-uniform
+    const u64 valid_mask = rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);   // whole line groups
     const uint4 v = vnext;
     // prefetch the next iteration (clamped: past the end it re-reads the last chunk)
     vnext = lines[min(chunk0 + stride + lane, n_chunks - 1u)];
@@ -400,26 +425,29 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
     c.x[0] = v.x; c.x[1] = v.y; c.x[2] = v.z; c.x[3] = v.w;
     c.g = g;
 
-    // ---- AllZero / AllWordSame ----
-    const u32 any = Grp<LPL>::red_or(c.x[0] | c.x[1] | c.x[2] | c.x[3]);
+    // ---- AllZero / AllWordSame: per-line predicates as lane masks, on the scalar unit ----
     c.w0 = Grp<LPL>::first(c.x[0]);
-    const u32 dif = Grp<LPL>::red_or((c.x[0] ^ c.w0) | (c.x[1] ^ c.w0) | (c.x[2] ^ c.w0) | (c.x[3] ^ c.w0));
-    const bool is_zero = (any == 0);
-    const bool is_same = P.has_aws && (dif == 0);
+    const u64 nz_b = __ballot((c.x[0] | c.x[1] | c.x[2] | c.x[3]) != 0);
+    const u64 df_b = __ballot(((c.x[0] ^ c.w0) | (c.x[1] ^ c.w0) | (c.x[2] ^ c.w0) | (c.x[3] ^ c.w0)) != 0);
+    const u64 zero_m = ~line_any<LPL>(nz_b);
+    const u64 same_m = P.has_aws ? ~line_any<LPL>(df_b) : 0ull;
+    const u64 need_mask = valid_mask & ~zero_m & ~same_m;
+    const bool is_zero = __builtin_amdgcn_inverse_ballot_w64(zero_m);
+    const bool need = __builtin_amdgcn_inverse_ballot_w64(need_mask);
 
     int chosen = is_zero ? 0 : 1;
     u32 size = is_zero ? enc_zero : enc_same;
-    u32 sum_r = 0, sum_r2 = 0;
+    u32 rr[4] = {0, 0, 0, 0};          // bytes whose sum / sum of squares go to the residue statistics
 
     // Skip the prediction modules only when no line of the wave needs them
     // (wave-uniform branch; DPP needs every lane of a line group active).
-    const bool need = valid && !is_zero && !is_same;
-    const u64 need_mask = __ballot(need);
     if (need_mask) {
       c.b0 = c.w0 & 0xffu;
       c.rootb = perm(c.w0, c.w0, 0u);            // byte 0 replicated
       c.xm1 = Grp<LPL>::prev(c.x[3]);
       Winner best;
+      best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
+      best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
       if constexpr (NPT > 0) {
         Pre4 pre = {0, 0, 0, 0};
         if constexpr (LPL == 4 && NPT > 1) {
@@ -437,13 +465,9 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
             pre.t3prev = Grp<4>::prev(pre.t3);
           }
         }
-        best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
-        best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
         eval_seq<LPL, NPT, 0, KINDS...>(c, P, tabs, shuf_line, lut, pre, need_mask & 0x1111111111111111ull, best,
                                         false);
       } else {
-        best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
-        best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
         for (int q = 0; q < n_pred; q++) {
           const MpcFastModule fm = P.fm[q];
           WinTab w;
@@ -457,7 +481,7 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
       }
 
       u32 enc = uncomp;
-      if (n_pred > 0) {
+      if ((n_pred > 0) && !(MPC_ABLATE & 2)) {
         // XOR stage of the winner, on bytes: b ^ (b >> 1), or b ^ 0x7f where the MSB is set;
         // column 0 untouched.  The flavour is usually the same for the whole wave.
         u32 t[4];
@@ -482,8 +506,8 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
         const u32 Sf = fold8(t[0] | t[1]), Sb = fold8(t[2] | t[3]);
         const u32 So = fold8(t[0] | (t[1] & 0x00ffffffu) | (t[2] & 0xffffff00u) | t[3]);
         const u32 n17 = Grp<LPL>::red_add((u32)__popc(Sf & Sb & So));
-        const bool open = need && (n17 < cert_min);
-        if (__any(open)) {
+        const u64 open_mask = __ballot(n17 < cert_min) & need_mask;
+        if (open_mask) {
           u32 Z;
           u32 bits = encode_rows(t, Z);
           // zero-row runs in row order r = plane * LPL + g: 4 bits per run, 7 if longer than one row
@@ -496,50 +520,65 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
           enc = Grp<LPL>::red_add(bits);
         }
       }
-      // residues over all positions: the winner's (root position holds best.root_r, not
-      // the raw root), or the raw bytes when the line stays uncompressed
-      const bool keep = (n_pred > 0) && (enc < uncomp);
-      u32 rr[4];
+      // residue statistics over all positions: the winner's residues (the root position
+      // holds best.root_r, not the raw root), or the raw bytes when the line stays
+      // uncompressed; nothing for AllZero / AllWordSame lines (VPC.cpp:412 is not reached)
+      const u64 keep_mask = (n_pred > 0) ? (__ballot(enc < uncomp) & need_mask) : 0ull;
+      if (keep_mask == 0 && need_mask == valid_mask) {
+        // whole wave uncompressed (the common case on incompressible data)
 #pragma unroll
-      for (int e = 0; e < 4; e++) rr[e] = keep ? best.r[e] : c.x[e];
-      if (keep && g == 0) rr[0] = (rr[0] & 0xffffff00u) | best.root_r;
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        sum_r = sum_bytes(rr[e], sum_r);
-        sum_r2 = sum_sq_bytes(rr[e], sum_r2);
-      }
-      sum_r = Grp<LPL>::red_add(sum_r);
-      sum_r2 = Grp<LPL>::red_add(sum_r2);
-      if (need) {
-        chosen = keep ? P.start + best.q : -1;
-        // no prediction module: the empty array encodes to 0 bits, cluster -1 (VPC.cpp:397-407)
-        size = keep ? enc : (n_pred > 0 ? uncomp : 0u);
-        size += keep ? (u32)P.enc_bits[chosen + 1] : enc_unc;
+        for (int e = 0; e < 4; e++) rr[e] = c.x[e];
+        chosen = -1;
+        size = (n_pred > 0 ? uncomp : 0u) + enc_unc;   // no prediction module: the empty array encodes to 0 bits
       } else {
-        sum_r = 0;
-        sum_r2 = 0;
+        const bool keep = __builtin_amdgcn_inverse_ballot_w64(keep_mask);
+#pragma unroll
+        for (int e = 0; e < 4; e++) rr[e] = keep ? best.r[e] : (need ? c.x[e] : 0u);
+        if (keep && g == 0) rr[0] = (rr[0] & 0xffffff00u) | best.root_r;
+        if (need) {
+          chosen = keep ? P.start + best.q : -1;
+          size = keep ? enc + (u32)P.enc_bits[chosen + 1] : (n_pred > 0 ? uncomp : 0u) + enc_unc;
+        }
       }
     }
 
-    // ---- per-line results: one lane per line ----
-    if (valid && g == 0) {
-      const u64 line = first_line + (chunk0 + lane) / LPL;
-      if (sizes_out) sizes_out[line] = (uint16_t)size;
-      if (sel_out) sel_out[line] = (int8_t)chosen;
-      const u32 key = ((u32)(chosen + 1) << 16) | size;
-      if (key != rs.key || rs.cnt == 255u) {
-        run_flush(rs, st, K, bins);
+    // ---- statistics: run-length per lane ----
+    const u32 key = ((u32)(chosen + 1) << 16) | size;
+    const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_mask);
+    if (valid) {
+      if (key != rs.key) {
+        run_flush(rs, st, K, bins, g == 0);
         rs.key = key;
         rs.cnt = 0;
         rs.acc_r = 0;
         rs.acc_r2 = 0;
       }
       rs.cnt++;
-      rs.acc_r += sum_r;
-      rs.acc_r2 += sum_r2;
+      if constexpr (!(MPC_ABLATE & 1)) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          rs.acc_r = sum_bytes(rr[e], rs.acc_r);
+          rs.acc_r2 = sum_sq_bytes(rr[e], rs.acc_r2);
+        }
+      }
+    }
+    if ((++iter & 127u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
+      run_flush(rs, st, K, bins, g == 0);
+      rs.cnt = 0;
+      rs.acc_r = 0;
+      rs.acc_r2 = 0;
+    }
+
+    // ---- per-line outputs (parity mode): one lane per line ----
+    if (sizes_out || sel_out) {
+      if (valid && g == 0) {
+        const u64 line = first_line + (chunk0 + lane) / LPL;
+        if (sizes_out) sizes_out[line] = (uint16_t)size;
+        if (sel_out) sel_out[line] = (int8_t)chosen;
+      }
     }
   }
-  run_flush(rs, st, K, bins);
+  run_flush(rs, st, K, bins, g == 0);
   stats_flush(st, K, bins, gstats);
 }
 
