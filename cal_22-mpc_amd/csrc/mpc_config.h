@@ -322,6 +322,7 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
   }
   while (plan.tab.size() % 4) plan.tab.push_back(0);
   if (plan.tab.empty()) plan.tab.assign(4, 0);
+  P.tab_words = (int32_t)plan.tab.size();
 }
 
 }  // namespace mpc

@@ -48,7 +48,7 @@ struct MpcVpcParams {
   int32_t has_aws;      /* module 1 is AllWordSame */
   int32_t hist_bins;    /* bins per cluster */
   int32_t cert_min17;   /* >= this many certain 17-bit rows => the encoding cannot beat 8*L bits */
-  int32_t pad0;
+  int32_t tab_words;    /* number of dwords in tab */
   int32_t enc_bits[MPC_MAX_MODULES + 1];  /* index cluster+1 */
   struct MpcFastModule fm[MPC_MAX_PRED];
   struct MpcGenModule gm[MPC_MAX_PRED];

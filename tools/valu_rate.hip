@@ -57,6 +57,34 @@ typedef unsigned int u32;
 #define OP_SADHI(x) asm volatile("v_sad_hi_u8 %0, %1, %2, %0" : "+v"(x) : "v"(b), "v"(c));
 #define OP_SUBSDWA(x) asm volatile("v_sub_u32_sdwa %0, %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0" : "+v"(x) : "v"(b));
 
+#define OP_AND(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_OR(x) asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_LSHL(x) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x));
+#define OP_MOV(x) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(b));
+#define OP_ANDLIT(x) asm volatile("v_and_b32 %0, 0x7f7f7f7f, %0" : "+v"(x));
+#define OP_XORLIT(x) asm volatile("v_xor_b32 %0, 0x80808081, %0" : "+v"(x));
+#define OP_ANDSGPR(x) asm volatile("v_and_b32 %0, %1, %0" : "+v"(x) : "s"(seed));
+#define OP_BITOP3LIT(x) asm volatile("v_bitop3_b32 %0, %0, %1, 0x80808080 bitop3:0xb4" : "+v"(x) : "v"(b));
+#define OP_BITOP3SGPR(x) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xb4" : "+v"(x) : "v"(b), "s"(seed));
+#define OP_CND2(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b) : );
+#define OP_CMPONLY(x) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b) : "vcc");
+#define OP_CMPS(x) asm volatile("v_cmp_lt_u32 s[20:21], %0, %1\n\tv_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b) : "s20", "s21");
+#define OP_SUBLIT(x) asm volatile("v_subrev_u32 %0, 0x01010101, %0" : "+v"(x));
+#define OP_ADD3(x) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_LSHLOR(x) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(x) : "v"(b));
+KERNEL(k_and, OP_AND)
+KERNEL(k_or, OP_OR)
+KERNEL(k_lshl, OP_LSHL)
+KERNEL(k_mov, OP_MOV)
+KERNEL(k_andlit, OP_ANDLIT)
+KERNEL(k_xorlit, OP_XORLIT)
+KERNEL(k_andsgpr, OP_ANDSGPR)
+KERNEL(k_bitop3sgpr, OP_BITOP3SGPR)
+KERNEL(k_cmponly, OP_CMPONLY)
+KERNEL(k_cmps, OP_CMPS)
+KERNEL(k_sublit, OP_SUBLIT)
+KERNEL(k_add3, OP_ADD3)
+KERNEL(k_lshlor, OP_LSHLOR)
 KERNEL(k_xor, OP_XOR)
 KERNEL(k_add, OP_ADD)
 KERNEL(k_sub, OP_SUB)
@@ -98,6 +126,10 @@ int main()
   u32 *out;
   hipMalloc(&out, (size_t)blocks * threads * 4);
   Entry es[] = {
+      {"v_and_b32", k_and, 1}, {"v_or_b32", k_or, 1}, {"v_lshlrev_b32", k_lshl, 1}, {"v_mov_b32", k_mov, 1},
+      {"v_and_b32 literal", k_andlit, 1}, {"v_xor_b32 literal", k_xorlit, 1}, {"v_and_b32 sgpr", k_andsgpr, 1},
+      {"v_bitop3 sgpr", k_bitop3sgpr, 1}, {"v_cmp(vcc)+v_xor", k_cmponly, 2},
+      {"v_cmp(sgpr)+v_xor", k_cmps, 2}, {"v_sub_u32 literal", k_sublit, 1}, {"v_add3_u32", k_add3, 1}, {"v_lshl_or_b32", k_lshlor, 1},
       {"v_xor_b32", k_xor, 1}, {"v_add_u32", k_add, 1}, {"v_sub_u32", k_sub, 1}, {"v_lshrrev_b32", k_lshr, 1},
       {"v_and_or_b32", k_andor, 1}, {"v_or3_b32", k_or3, 1}, {"v_bitop3_b32", k_bitop3, 1}, {"v_bfi_b32", k_bfi, 1},
       {"v_xnor_b32", k_xnor, 1}, {"v_bfe_u32", k_bfe, 1},
