@@ -73,26 +73,6 @@ __device__ __forceinline__ u32 encode_rows(const u32 t[4], u32 &zero_mask)
   return 7u * __popc(single) + 8u * __popc(two) + 12u * __popc(half) + 17u * __popc(full);
 }
 
-// Loop-invariant constants pinned in VGPRs: on gfx950 a VALU instruction with an SGPR source
-// issues at the slow rate (profiles/r01_valu_issue_rates_gfx950.txt), literals / VGPRs do not.
-struct VConst {
-  u32 h80, l7f;      // 0x80808080, 0x7f7f7f7f
-  u32 colmask0;      // 0xffffff00 on the lane that holds column 0 (the root), else 0xffffffff
-};
-__device__ __forceinline__ u32 pin(u32 v)
-{
-  asm volatile("" : "+v"(v));
-  return v;
-}
-__device__ __forceinline__ u32 bsubk(const VConst &k, u32 a, u32 b)   // per-byte (a - b) mod 256
-{
-  return ((a | k.h80) - (b & k.l7f)) ^ ((a ^ ~b) & k.h80);
-}
-__device__ __forceinline__ u32 baddk(const VConst &k, u32 a, u32 b)   // per-byte (a + b) mod 256
-{
-  return ((a & k.l7f) + (b & k.l7f)) ^ ((a ^ b) & k.h80);
-}
-
 struct WinTab { u32 sel[4], c1[4], c2[4]; };
 // the same tables for (column group 0, word g): what lane g needs for the row-0 prefilter
 struct WinTab0 { u32 sel, c1, c2; };
@@ -105,53 +85,66 @@ struct LineCtx {
   u32 rootb;   // root replicated into 4 bytes
   u32 xm1;     // previous lane's last word (garbage for g == 0, never selected)
   u32 g;
-  VConst k;
 };
 
-// predicted word from the own / previous word (v_perm) + diff constant or per-byte shifts
-// shift amounts of a WeightBase module, as VGPR values (see VConst)
-struct WShift { u32 ls1, rs1, ls2, rs2; };
+// 4x4 transpose of 32-bit words across the 4 lanes of a quad: out lane g, slot e
+// = in lane e, slot g.
+__device__ __forceinline__ void quad_transpose(u32 U[4], u32 lane)
+{
+  const bool o1 = lane & 1, o2 = lane & 2;
+  {
+    u32 s0 = o1 ? U[0] : U[1], s1 = o1 ? U[2] : U[3];
+    u32 r0 = dpp<QP(1, 0, 3, 2)>(s0), r1 = dpp<QP(1, 0, 3, 2)>(s1);
+    U[0] = o1 ? r0 : U[0]; U[1] = o1 ? U[1] : r0;
+    U[2] = o1 ? r1 : U[2]; U[3] = o1 ? U[3] : r1;
+  }
+  {
+    u32 s0 = o2 ? U[0] : U[2], s1 = o2 ? U[1] : U[3];
+    u32 r0 = dpp<QP(2, 3, 0, 1)>(s0), r1 = dpp<QP(2, 3, 0, 1)>(s1);
+    U[0] = o2 ? r0 : U[0]; U[2] = o2 ? U[2] : r0;
+    U[1] = o2 ? r1 : U[1]; U[3] = o2 ? U[3] : r1;
+  }
+}
 
+// predicted word from the own / previous word (v_perm) + diff constant or per-byte shifts
 template <int KIND>
-__device__ __forceinline__ u32 window_predict(const VConst &k, u32 own, u32 prevw, u32 sel, u32 c1, u32 c2,
-                                              const MpcFastModule &fm, const WShift &sh)
+__device__ __forceinline__ u32 window_predict(u32 own, u32 prevw, u32 sel, u32 c1, u32 c2, const MpcFastModule &fm)
 {
   const u32 b = perm(own, prevw, sel);
-  if constexpr (KIND == MPC_FK_DIFF) {
-    return baddk(k, b, c1);
-  } else {
-    // the branches are wave-uniform (module constants)
-    u32 t1 = b, t2 = b;
-    if (fm.ls1) t1 <<= sh.ls1;
-    if (fm.rs1) t1 >>= sh.rs1;
-    if (fm.ls2) t2 <<= sh.ls2;
-    if (fm.rs2) t2 >>= sh.rs2;
-    return (t1 & c1) | (t2 & c2);
-  }
+  if constexpr (KIND == MPC_FK_DIFF)
+    return badd(b, c1);
+  else
+    return (((b << fm.ls1) >> fm.rs1) & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
 }
 
 // Residue bytes (root first == natural order for RootIndex 0) of one module for
 // this lane's 16 columns; root_r = residue GetMAE/GetMSE see at the root.
 template <int LPL, int KIND>
 __device__ __forceinline__ void module_residue(const LineCtx<LPL> &c, const MpcFastModule &fm, const WinTab &wt,
-                                               const WShift &sh, u32 *shuf_line, u32 r[4], u32 &root_r)
+                                               u32 *shuf_line, u32 r[4], u32 &root_r)
 {
   constexpr int W = 4 * LPL;
   root_r = 0;
   if constexpr (KIND == MPC_FK_ONEBASE) {
     // predicted = line[0] everywhere; position 0 of the residue array is the raw root
 #pragma unroll
-    for (int e = 0; e < 4; e++) r[e] = bsubk(c.k, c.x[e], c.rootb);
-    r[0] = (r[0] & c.k.colmask0) | (c.b0 & ~c.k.colmask0);
+    for (int e = 0; e < 4; e++) r[e] = bsub(c.x[e], c.rootb);
+    if (c.g == 0) r[0] = (r[0] & 0xffffff00u) | c.b0;
   } else if constexpr (KIND == MPC_FK_CONSEC) {
     // inp = bytes reordered plane 3,2,1,0 of each word; predicted[i] = inp[i-1].
     // 4x4 byte transpose of this lane's words: T[k] = byte k of the 4 words
     const u32 lo01 = perm(c.x[1], c.x[0], 0x05010400u), hi01 = perm(c.x[1], c.x[0], 0x07030602u);
     const u32 lo23 = perm(c.x[3], c.x[2], 0x05010400u), hi23 = perm(c.x[3], c.x[2], 0x07030602u);
     u32 in[4];
-    {
-      // scatter into the shuffled line in LDS (byte k of word w -> inp[(3-k)*W + w]), read back
-      // this lane's 16 bytes: the LDS pipe does the 4x4 lane transpose, not the VALU
+    if constexpr (LPL == 4) {
+      // lane g needs byte (3-g) of all 16 words: slot j <- T[3-j], then transpose the quad
+      in[3] = perm(lo23, lo01, 0x05040100u);
+      in[2] = perm(lo23, lo01, 0x07060302u);
+      in[1] = perm(hi23, hi01, 0x05040100u);
+      in[0] = perm(hi23, hi01, 0x07060302u);
+      quad_transpose(in, c.g);
+    } else {
+      // general LPL: scatter into the shuffled line in LDS (byte k of word w -> inp[(3-k)*W + w])
       u32 T[4];
       T[0] = perm(lo23, lo01, 0x05040100u);
       T[1] = perm(lo23, lo01, 0x07060302u);
@@ -168,11 +161,12 @@ __device__ __forceinline__ void module_residue(const LineCtx<LPL> &c, const MpcF
       __builtin_amdgcn_wave_barrier();
     }
     const u32 carry = Grp<LPL>::prev(in[3]);     // inp[16g-1]: last byte of the previous lane
-    const u32 p0 = alignbyte(in[0], carry, 3) & c.k.colmask0;   // root: predicted byte 0 -> residue[0] = raw root
-    r[0] = bsubk(c.k, c.x[0], p0);
-    r[1] = bsubk(c.k, c.x[1], alignbyte(in[1], in[0], 3));
-    r[2] = bsubk(c.k, c.x[2], alignbyte(in[2], in[1], 3));
-    r[3] = bsubk(c.k, c.x[3], alignbyte(in[3], in[2], 3));
+    u32 p0 = alignbyte(in[0], carry, 3);
+    if (c.g == 0) p0 &= 0xffffff00u;            // root: predicted byte 0 -> residue[0] = raw root
+    r[0] = bsub(c.x[0], p0);
+    r[1] = bsub(c.x[1], alignbyte(in[1], in[0], 3));
+    r[2] = bsub(c.x[2], alignbyte(in[2], in[1], 3));
+    r[3] = bsub(c.x[3], alignbyte(in[3], in[2], 3));
     // predicted[root] = inp[0] = byte 3 of word 0 (PredictorModule.cpp:159-164)
     root_r = (c.b0 - (c.w0 >> 24)) & 0xffu;
   } else {
@@ -180,7 +174,7 @@ __device__ __forceinline__ void module_residue(const LineCtx<LPL> &c, const MpcF
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const u32 prevw = (e == 0) ? c.xm1 : c.x[e - 1];
-      r[e] = bsubk(c.k, c.x[e], window_predict<KIND>(c.k, c.x[e], prevw, wt.sel[e], wt.c1[e], wt.c2[e], fm, sh));
+      r[e] = bsub(c.x[e], window_predict<KIND>(c.x[e], prevw, wt.sel[e], wt.c1[e], wt.c2[e], fm));
     }
   }
 }
@@ -196,8 +190,7 @@ struct Pre4 {
 };
 
 template <int KIND>
-__device__ __forceinline__ u32 row0_msbs(const LineCtx<4> &c, const Pre4 &p, const MpcFastModule &fm, const WinTab0 &w0,
-                                          const WShift &sh)
+__device__ __forceinline__ u32 row0_msbs(const LineCtx<4> &c, const Pre4 &p, const MpcFastModule &fm, const WinTab0 &w0)
 {
   u32 pred;
   if constexpr (KIND == MPC_FK_ONEBASE) {
@@ -205,10 +198,10 @@ __device__ __forceinline__ u32 row0_msbs(const LineCtx<4> &c, const Pre4 &p, con
   } else if constexpr (KIND == MPC_FK_CONSEC) {
     pred = alignbyte(p.t3, p.t3prev, 3);   // inp[4g-1 .. 4g+2]
   } else {
-    pred = window_predict<KIND>(c.k, p.y, p.yprev, w0.sel, w0.c1, w0.c2, fm, sh);
+    pred = window_predict<KIND>(p.y, p.yprev, w0.sel, w0.c1, w0.c2, fm);
   }
-  pred &= c.k.colmask0;                    // byte 0 of the residue array is the raw root
-  return bsubk(c.k, p.y, pred) & c.k.h80;
+  if (c.g == 0) pred &= 0xffffff00u;       // byte 0 of the residue array is the raw root
+  return bsub(p.y, pred) & H80;
 }
 
 // leading zero rows of the scanned array.  The first non-zero row of the XORed
@@ -245,22 +238,9 @@ __device__ __forceinline__ void load_wintab(const u32 *tab, const MpcFastModule 
 // per-kernel constant state of the compile-time module sequence
 template <int NPT>
 struct SeqTabs {
-  WShift sh[NPT > 0 ? NPT : 1];
-  const u32 *tabL;     // the predictor tables, copied to LDS: read per use, not held in VGPRs
-  u32 g;
-  int W;
+  WinTab wt[NPT > 0 ? NPT : 1];
+  WinTab0 w0[NPT > 0 ? NPT : 1];
 };
-
-// this lane's {sel, c1, c2} for its 4 words, from the LDS copy (3 x ds_read_b128)
-__device__ __forceinline__ void lds_wintab(const u32 *tabL, int tab_off, int W, u32 g, WinTab &wt)
-{
-  const uint4 a = *reinterpret_cast<const uint4 *>(tabL + tab_off + 4 * g);
-  const uint4 b = *reinterpret_cast<const uint4 *>(tabL + tab_off + W + 4 * g);
-  const uint4 c = *reinterpret_cast<const uint4 *>(tabL + tab_off + 2 * W + 4 * g);
-  wt.sel[0] = a.x; wt.sel[1] = a.y; wt.sel[2] = a.z; wt.sel[3] = a.w;
-  wt.c1[0] = b.x; wt.c1[1] = b.y; wt.c1[2] = b.z; wt.c1[3] = b.w;
-  wt.c2[0] = c.x; wt.c2[1] = c.y; wt.c2[2] = c.z; wt.c2[3] = c.w;
-}
 
 struct Winner {
   u32 r[4];
@@ -275,15 +255,13 @@ struct Winner {
 template <int LPL>
 __device__ __forceinline__ void take_if_better(Winner &best, const u32 r[4], u32 z, int q, u32 root_r, u32 cx)
 {
-  // ties go to the later module (VPC.cpp:389): take when best.z <= z.  Full-width mask
-  // (z is at most 64), then bit selects: cheaper than v_cndmask on gfx950.
-  const u32 m = (u32)((int)(best.z - z - 1u) >> 31);
-  best.z = (z & m) | (best.z & ~m);
-  best.q = (int)(((u32)q & m) | ((u32)best.q & ~m));
-  best.root_r = (root_r & m) | (best.root_r & ~m);
-  best.cx = (cx & m) | (best.cx & ~m);
+  const bool take = best.z <= z;     // ties go to the later module (VPC.cpp:389)
+  best.z = take ? z : best.z;
+  best.q = take ? q : best.q;
+  best.root_r = take ? root_r : best.root_r;
+  best.cx = take ? cx : best.cx;
 #pragma unroll
-  for (int e = 0; e < 4; e++) best.r[e] = (r[e] & m) | (best.r[e] & ~m);
+  for (int e = 0; e < 4; e++) best.r[e] = take ? r[e] : best.r[e];
 }
 
 template <int LPL, int NPT, int Q>
@@ -300,14 +278,7 @@ __device__ __forceinline__ void eval_seq(const LineCtx<LPL> &c, const MpcVpcPara
     if constexpr (MPC_ABLATE & 8) full = false;
     if constexpr (LPL == 4 && !(MPC_ABLATE & 8)) {
       // prefilter: skip the module when no line of the wave can have a leading zero row
-      WinTab0 w0 = {0, 0, 0};
-      if constexpr (KIND == MPC_FK_DIFF || KIND == MPC_FK_WEIGHT) {
-        const u32 *t = tabs.tabL + P.fm[Q].tab_off + (tabs.g & 3);   // column group 0, word g
-        w0.sel = t[0];
-        w0.c1 = t[tabs.W];
-        w0.c2 = t[2 * tabs.W];
-      }
-      const u32 msb = row0_msbs<KIND>(c, pre, P.fm[Q], w0, tabs.sh[Q]);
+      const u32 msb = row0_msbs<KIND>(c, pre, P.fm[Q], tabs.w0[Q]);
       u64 b = __ballot(msb != 0);
       b |= b >> 1;
       b |= b >> 2;                                   // bit 4k: some lane of line k has an MSB set
@@ -316,9 +287,7 @@ __device__ __forceinline__ void eval_seq(const LineCtx<LPL> &c, const MpcVpcPara
     }
     if (full) {
       u32 r[4], root_r;
-      WinTab wt;
-      if constexpr (KIND == MPC_FK_DIFF || KIND == MPC_FK_WEIGHT) lds_wintab(tabs.tabL, P.fm[Q].tab_off, tabs.W, tabs.g, wt);
-      module_residue<LPL, KIND>(c, P.fm[Q], wt, tabs.sh[Q], shuf_line, r, root_r);
+      module_residue<LPL, KIND>(c, P.fm[Q], tabs.wt[Q], shuf_line, r, root_r);
       take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), Q, root_r, (u32)P.fm[Q].cx);
       any_full = true;
     }
@@ -326,10 +295,8 @@ __device__ __forceinline__ void eval_seq(const LineCtx<LPL> &c, const MpcVpcPara
   } else {
     // the last module is always evaluated; its z only matters against an earlier candidate
     u32 r[4], root_r;
-    WinTab wt;
-    if constexpr (KIND == MPC_FK_DIFF || KIND == MPC_FK_WEIGHT) lds_wintab(tabs.tabL, P.fm[Q].tab_off, tabs.W, tabs.g, wt);
     if constexpr (MPC_ABLATE & 4) { r[0] = c.x[0]; r[1] = c.x[1]; r[2] = c.x[2]; r[3] = c.x[3]; root_r = 0; }
-    else module_residue<LPL, KIND>(c, P.fm[Q], wt, tabs.sh[Q], shuf_line, r, root_r);
+    else module_residue<LPL, KIND>(c, P.fm[Q], tabs.wt[Q], shuf_line, r, root_r);
     if (any_full) {
       take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), Q, root_r, (u32)P.fm[Q].cx);
     } else {
@@ -347,8 +314,7 @@ __device__ __forceinline__ void eval_update(const LineCtx<LPL> &c, const MpcFast
                                             u32 *shuf_line, const u32 *lut, int q, Winner &best)
 {
   u32 r[4], root_r;
-  const WShift sh = {(u32)fm.ls1, (u32)fm.rs1, (u32)fm.ls2, (u32)fm.rs2};
-  module_residue<LPL, KIND>(c, fm, wt, sh, shuf_line, r, root_r);
+  module_residue<LPL, KIND>(c, fm, wt, shuf_line, r, root_r);
   take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), q, root_r, (u32)fm.cx);
 }
 
@@ -402,14 +368,10 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
   WgStats st;
   st.sums = reinterpret_cast<u64 *>(smem);
   st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * K * 8 + 15) / 16));
-  // row-order spread table for leading_zero_rows; then per wave 2 KiB staging of the
-  // lines (so any lane can fetch any word of its line with a ds_read instead of DPP) and
-  // 2 KiB for the byte-plane shuffle.  Lines are W + 4 words apart: conflict-free banks.
+  // row-order spread table for leading_zero_rows, then per-wave scratch for the
+  // byte-plane shuffle when LPL != 4 (64 lanes x 16 B)
   u32 *lut = reinterpret_cast<u32 *>(smem + vpc_stats_smem(K, bins));
-  u32 *stage = lut + 256 + (threadIdx.x >> 6) * 1024;
-  u32 *shuf = stage + 512;
-  u32 *tabL = lut + 256 + 4 * 1024;                 // P.tab_words dwords
-  for (int i = threadIdx.x; i < P.tab_words; i += blockDim.x) tabL[i] = P.tab[i];
+  u32 *shuf = lut + 256 + (threadIdx.x >> 6) * 256;
   {
     // bit j of S (plane 7-j) -> row LPL*(7-j) of lane 0, i.e. bit 31 - LPL*(7-j)
     u32 v = 0;
@@ -421,30 +383,25 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
 
   const u32 lane = threadIdx.x & 63;
   const u32 g = lane & (LPL - 1);      // column group inside the line
-  u32 *shuf_line = shuf + (lane / LPL) * (W + 4);
-  u32 *my_line = stage + 4 + (lane / LPL) * (W + 4);       // 16 B of headroom: word -1 of line 0 is readable
+  u32 *shuf_line = shuf + (lane / LPL) * W;
   const u32 colmask0 = (g == 0) ? 0xffffff00u : 0xffffffffu;   // column 0 is exempt from the XOR stage
-  VConst kc;
-  kc.h80 = pin(H80);
-  kc.l7f = pin(L7F);
-  kc.colmask0 = colmask0;
   const u32 uncomp = 8u * L;
   const int n_pred = NPT > 0 ? NPT : P.n_pred;
   const u32 enc_zero = (u32)P.enc_bits[1], enc_same = 32u + (u32)P.enc_bits[2], enc_unc = (u32)P.enc_bits[0];
   const u32 cert_min = (u32)P.cert_min17;
 
-  // predictor tables: one LDS copy per workgroup (compile-time sequence only)
+  // loop-invariant predictor tables in registers (compile-time sequence only)
   SeqTabs<NPT> tabs;
-  tabs.tabL = tabL;
-  tabs.g = g;
-  tabs.W = W;
   if constexpr (NPT > 0) {
 #pragma unroll
     for (int q = 0; q < NPT; q++) {
-      tabs.sh[q].ls1 = pin((u32)P.fm[q].ls1);
-      tabs.sh[q].rs1 = pin((u32)P.fm[q].rs1);
-      tabs.sh[q].ls2 = pin((u32)P.fm[q].ls2);
-      tabs.sh[q].rs2 = pin((u32)P.fm[q].rs2);
+      if (kinds[q] == MPC_FK_DIFF || kinds[q] == MPC_FK_WEIGHT) {
+        load_wintab(P.tab, P.fm[q], W, g, tabs.wt[q]);
+        const u32 *t = P.tab + P.fm[q].tab_off;     // column group 0, word g (row-0 prefilter)
+        tabs.w0[q].sel = t[g & 3];
+        tabs.w0[q].c1 = t[W + (g & 3)];
+        tabs.w0[q].c2 = t[2 * W + (g & 3)];
+      }
     }
   }
 
@@ -458,7 +415,9 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
   uint4 vnext = make_uint4(0, 0, 0, 0);
   if (chunk0 < n_chunks) vnext = lines[min(chunk0 + lane, n_chunks - 1u)];
   for (; chunk0 < n_chunks; chunk0 += stride) {
-    const u32 rem = n_chunks - chunk0;                                   // wave-uniform
+    // chunk0 is wave-uniform by construction; readfirstlane makes the compiler keep the
+    // whole mask algebra below on the scalar unit
+    const u32 rem = n_chunks - __builtin_amdgcn_readfirstlane(chunk0);
     const u64 valid_mask = rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);   // whole line groups
     const uint4 v = vnext;
     // prefetch the next iteration (clamped: past the end it re-reads the last chunk)
@@ -467,16 +426,9 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
     LineCtx<LPL> c;
     c.x[0] = v.x; c.x[1] = v.y; c.x[2] = v.z; c.x[3] = v.w;
     c.g = g;
-    c.k = kc;
-
-    // stage the line in LDS: word broadcasts / neighbours come back through the LDS pipe
-    *reinterpret_cast<uint4 *>(my_line + 4 * g) = v;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- AllZero / AllWordSame: per-line predicates as lane masks, on the scalar unit ----
-    c.w0 = my_line[0];
+    c.w0 = Grp<LPL>::first(c.x[0]);
     const u64 nz_b = __ballot((c.x[0] | c.x[1] | c.x[2] | c.x[3]) != 0);
     const u64 df_b = __ballot(((c.x[0] ^ c.w0) | (c.x[1] ^ c.w0) | (c.x[2] ^ c.w0) | (c.x[3] ^ c.w0)) != 0);
     const u64 zero_m = ~line_any<LPL>(nz_b);
@@ -494,16 +446,18 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
     if (need_mask) {
       c.b0 = c.w0 & 0xffu;
       c.rootb = perm(c.w0, c.w0, 0u);            // byte 0 replicated
-      c.xm1 = my_line[4 * (int)g - 1];              // previous lane's last word (unused garbage for g == 0)
+      c.xm1 = Grp<LPL>::prev(c.x[3]);
       Winner best;
       best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
       best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
       if constexpr (NPT > 0) {
         Pre4 pre = {0, 0, 0, 0};
         if constexpr (LPL == 4 && NPT > 1) {
-          // word g of column group 0, and its predecessor (unused garbage for g == 0)
-          pre.y = my_line[g];
-          pre.yprev = my_line[(int)g - 1];
+          // word g of column group 0, and its predecessor
+          const u32 a0 = dpp<QP(0, 0, 0, 0)>(c.x[0]), a1 = dpp<QP(0, 0, 0, 0)>(c.x[1]);
+          const u32 a2 = dpp<QP(0, 0, 0, 0)>(c.x[2]), a3 = dpp<QP(0, 0, 0, 0)>(c.x[3]);
+          pre.y = (g & 2) ? ((g & 1) ? a3 : a2) : ((g & 1) ? a1 : a0);
+          pre.yprev = (g & 2) ? ((g & 1) ? a2 : a1) : a0;
           bool any_consec = false;
 #pragma unroll
           for (int q = 0; q + 1 < NPT; q++) any_consec = any_consec || (kinds[q] == MPC_FK_CONSEC);
@@ -537,14 +491,14 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
         if ((cx_mask & need_mask) == need_mask) {
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            const u32 f = (best.r[e] >> 1) & kc.l7f;
+            const u32 f = (best.r[e] >> 1) & L7F;
             t[e] = best.r[e] ^ (e == 0 ? (f & colmask0) : f);
           }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const u32 m = (best.r[e] >> 7) & 0x01010101u;
-            const u32 f = best.cx ? ((best.r[e] >> 1) & kc.l7f) : ((m << 7) - m);
+            const u32 f = best.cx ? ((best.r[e] >> 1) & L7F) : ((m << 7) - m);
             t[e] = best.r[e] ^ (e == 0 ? (f & colmask0) : f);
           }
         }
@@ -662,11 +616,8 @@ static hipError_t launch_seq(const uint4 *l, u32 n_chunks, u64 first_line, const
   return hipGetLastError();
 }
 
-// statistics + spread table (1 KiB) + per wave 2 KiB line staging and 2 KiB shuffle scratch + tables
-extern "C" size_t mpc_vpc_fast_smem(const MpcVpcParams *P)
-{
-  return vpc_stats_smem(P->M + 1, P->hist_bins) + 17 * 1024 + 16 * (size_t)((P->tab_words * 4 + 15) / 16);
-}
+// statistics + spread table (1 KiB) + shuffle scratch (4 waves x 1 KiB)
+extern "C" size_t mpc_vpc_fast_smem(const MpcVpcParams *P) { return vpc_stats_smem(P->M + 1, P->hist_bins) + 5 * 1024; }
 
 extern "C" hipError_t mpc_launch_vpc_fast(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
                                           int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
