@@ -153,50 +153,78 @@ vpc_generic_kernel(const uint8_t *__restrict__ lines, u64 n_lines, MpcVpcParams 
 }
 
 // ---------------------------------------------------------------------------
-// BDI (reference BDI.cpp): one lane per line
+// BDI (reference BDI.cpp): one lane per line, line in registers.
+//
+// reduceSign (BDI.cpp:203-218) strips the leading ones of a negative 64-bit value down to
+// one sign bit and returns -1 unchanged, so "reduceSign(x) <= 2^(8D)-1" is the range test
+//        0 <= x <= 2^(8D)-1     or     -2^(8D-1) <= x <= -2          (x as signed 64-bit)
+// (a delta of exactly -1 is rejected, +128..+255 is accepted for D = 1, as in the
+// reference).  The kernel evaluates that range test directly; no bit loops.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ u64 bdi_reduce_sign(u64 x)   // BDI.cpp:203-218
+template <int D>   // x = (hi, lo)
+__device__ __forceinline__ bool bdi_fits64(u32 hi, u32 lo)
 {
-  if (!(x >> 63)) return x;
-  const u64 nx = ~x;
-  if (nx == 0) return x;                                 // -1: no clear bit, returned unchanged
-  const int i = 63 - __clzll((long long)nx);             // highest clear bit of x (<= 62)
-  const int keep = i + 2;                                // low (i+2) bits
-  return keep >= 64 ? x : (x & ((1ull << keep) - 1ull));
+  if constexpr (D == 4) {
+    return (hi == 0u) || (hi == 0xffffffffu && lo >= 0x80000000u && lo != 0xffffffffu);
+  } else {
+    constexpr u32 h = 1u << (8 * D - 1), lim = (1u << (8 * D)) - 1u;
+    // t = lo + h: the accepted ranges become [0, h-2] (carry, hi = -1) and [h, h+lim] (no carry, hi = 0)
+    const u32 t = lo + h;
+    const u32 carry = t < lo ? 1u : 0u;
+    return (hi + carry == 0u) && (t <= h + lim) && (t != h - 1u);
+  }
 }
 
-template <int B>   // base size in bytes
-__device__ __forceinline__ u64 bdi_value(const u32 *w, int i)
+// values narrower than 64 bits are zero-extended (BDI.cpp:150-151 is a no-op), so an
+// immediate is simply v <= limit and a delta base - v lies in (-2^32, 2^32)
+template <int D>
+__device__ __forceinline__ bool bdi_fits_delta32(u32 base, u32 v)
 {
-  if (B == 8) return ((u64)w[2 * i + 1] << 32) | w[2 * i];
-  if (B == 4) return w[i];
-  return (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+  constexpr u32 h = 1u << (8 * D - 1), lim = (1u << (8 * D)) - 1u;
+  const u32 d = base - v;                       // wraps when base < v
+  return base >= v ? (d <= lim) : (d >= 0u - h && d <= 0xfffffffeu);
 }
 
-template <int B, int NW>
-__device__ __forceinline__ u32 bdi_check(const u32 *w, u32 D)   // BDI.cpp:108-201
+struct BdiScan {      // state of one (base size, delta size) scan over the values of a line
+  u32 imm;
+  bool have_base, not_all;
+};
+
+template <int B, int D, int NW>
+__device__ __forceinline__ u32 bdi_check(const u32 *w)   // BDI.cpp:108-201
 {
   constexpr u32 n = (NW * 4) / B;
-  const u64 limit = D == 1 ? 0xffull : (D == 2 ? 0xffffull : 0xffffffffull);
+  constexpr u32 lim = D == 4 ? 0xffffffffu : ((1u << (8 * D)) - 1u);
   u32 imm = 0;
-  u64 base = 0;
   bool have_base = false, not_all = false;
+  u32 base_lo = 0, base_hi = 0;
 #pragma unroll
   for (u32 i = 0; i < n; i++) {
-    const u64 v = bdi_value<B>(w, (int)i);
-    const bool is_imm = (B == 8 ? bdi_reduce_sign(v) : v) <= limit;
-    if (is_imm) {
-      imm++;
-    } else if (!have_base) {
-      have_base = true;
-      base = v;
+    u32 lo, hi = 0;
+    if constexpr (B == 8) { lo = w[2 * i]; hi = w[2 * i + 1]; }
+    else if constexpr (B == 4) lo = w[i];
+    else lo = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+    bool is_imm;
+    if constexpr (B == 8) is_imm = bdi_fits64<D>(hi, lo);
+    else is_imm = lo <= lim;
+    imm += is_imm ? 1u : 0u;
+    const bool first = !is_imm && !have_base;
+    bool ok;   // base - v fits the delta width
+    if constexpr (B == 8) {
+      const u32 dlo = base_lo - lo;
+      const u32 dhi = base_hi - hi - (base_lo < lo ? 1u : 0u);
+      ok = bdi_fits64<D>(dhi, dlo);
     } else {
-      not_all = not_all || (bdi_reduce_sign(base - v) > limit);
+      ok = bdi_fits_delta32<D>(base_lo, lo);
     }
+    not_all = not_all || (!is_imm && have_base && !ok);
+    base_lo = first ? lo : base_lo;
+    if constexpr (B == 8) base_hi = first ? hi : base_hi;
+    have_base = have_base || !is_imm;
   }
   // 32-bit unsigned arithmetic incl. the wrap when every value is an immediate (BDI.cpp:200)
-  if (not_all) return n + 8u * ((imm * D) + ((n - imm) * (u32)B));
-  return n + 8u * ((imm * D) + ((u32)B + (n - imm - 1u) * D));
+  if (not_all) return n + 8u * ((imm * (u32)D) + ((n - imm) * (u32)B));
+  return n + 8u * ((imm * (u32)D) + ((u32)B + (n - imm - 1u) * (u32)D));
 }
 
 template <int NW>   // words per line
@@ -208,6 +236,8 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
   if (threadIdx.x < MPC_BDI_RAW_LEN) s_counts[threadIdx.x] = 0;
   __syncthreads();
   constexpr u32 uncomp = 32u * NW;
+  // run-length accumulation per lane: (select, size) key, count
+  u32 run_key = 0xffffffffu, run_cnt = 0;
   for (u64 line = (u64)blockIdx.x * blockDim.x + threadIdx.x; line < n_lines; line += (u64)gridDim.x * blockDim.x) {
     u32 w[NW];
     const uint4 *src = lines + line * (NW / 4);
@@ -232,19 +262,31 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
       select = 1;
     } else {
       u32 c;
-      c = bdi_check<8, NW>(w, 1); if (best > c) { best = c; select = 2; }
-      c = bdi_check<8, NW>(w, 2); if (best > c) { best = c; select = 3; }
-      c = bdi_check<8, NW>(w, 4); if (best > c) { best = c; select = 4; }
-      c = bdi_check<4, NW>(w, 1); if (best > c) { best = c; select = 5; }
-      c = bdi_check<4, NW>(w, 2); if (best > c) { best = c; select = 6; }
-      c = bdi_check<2, NW>(w, 1); if (best > c) { best = c; select = 7; }
+      c = bdi_check<8, 1, NW>(w); if (best > c) { best = c; select = 2; }
+      c = bdi_check<8, 2, NW>(w); if (best > c) { best = c; select = 3; }
+      c = bdi_check<8, 4, NW>(w); if (best > c) { best = c; select = 4; }
+      c = bdi_check<4, 1, NW>(w); if (best > c) { best = c; select = 5; }
+      c = bdi_check<4, 2, NW>(w); if (best > c) { best = c; select = 6; }
+      c = bdi_check<2, 1, NW>(w); if (best > c) { best = c; select = 7; }
       if (best == uncomp) select = 8;
     }
     const u32 size = best + 4u;
     if (sizes_out) sizes_out[line] = (uint16_t)size;
     if (sel_out) sel_out[line] = (int8_t)select;
-    atomicAdd(&s_counts[select], 1ull);
-    atomicAdd(&s_counts[9], (u64)size);
+    const u32 key = ((u32)select << 16) | size;
+    if (key != run_key) {
+      if (run_cnt) {
+        atomicAdd(&s_counts[run_key >> 16], (u64)run_cnt);
+        atomicAdd(&s_counts[9], (u64)run_cnt * (u64)(run_key & 0xffffu));
+      }
+      run_key = key;
+      run_cnt = 0;
+    }
+    run_cnt++;
+  }
+  if (run_cnt) {
+    atomicAdd(&s_counts[run_key >> 16], (u64)run_cnt);
+    atomicAdd(&s_counts[9], (u64)run_cnt * (u64)(run_key & 0xffffu));
   }
   __syncthreads();
   if (threadIdx.x < MPC_BDI_RAW_LEN && s_counts[threadIdx.x]) atomicAdd(&gstats[threadIdx.x], s_counts[threadIdx.x]);
