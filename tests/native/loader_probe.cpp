@@ -1,0 +1,49 @@
+// loader_probe.cpp -- test driver for the host-side mirror of trace::LoaderNPY (CPU only).
+// Prints what the per-line interface (GetCacheline, as the reference driver uses it,
+// src/main.cpp:237-243) and the additive batch interface (GetBatch) deliver.
+//   loader_probe FILE.npy line|batch [batch_lines]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "LoaderNPY.h"
+
+static unsigned long long fnv(const uint8_t *p, size_t n, unsigned long long h)
+{
+  for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 3) return 2;
+  const std::string path = argv[1];
+  trace::LoaderNPY loader(path);
+  const unsigned L = loader.GetCachelineSize();
+  printf("lines %llu line_size %u\n", loader.GetNumLines(), L);
+  unsigned long long h = 1469598103934665603ull, n = 0;
+  if (!strcmp(argv[2], "line")) {
+    trace::MemReq_t *req = new trace::MemReq_t;
+    req->Reset();
+    while (1) {
+      req = loader.GetCacheline(req);
+      if (req->isEnd) break;                 // the reference tests isEnd BEFORE compressing
+      if (req->data.size() != L || req->reqSize != L) return 3;
+      h = fnv(req->data.data(), L, h);
+      n++;
+    }
+    delete req;   // (the reference driver leaks it; the sanitizer build must not)
+  } else {
+    const unsigned long long cap = argc > 3 ? strtoull(argv[3], nullptr, 10) : 1000;
+    std::vector<uint8_t> buf(cap * L);
+    for (;;) {
+      unsigned long long got = loader.GetBatch(buf.data(), cap);
+      if (!got) break;
+      h = fnv(buf.data(), got * L, h);
+      n += got;
+    }
+  }
+  printf("delivered %llu hash %llu\n", n, h);
+  return 0;
+}

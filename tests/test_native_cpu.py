@@ -1,0 +1,109 @@
+"""CPU-only native checks: the host mirror of trace::LoaderNPY against numpy (incl. the
+reference's dropped last row), and AddressSanitizer / UBSan runs of the configuration
+reader and of the oracle (sanitizers are not available on the GPU pool, so here)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HOST = os.path.join(ROOT, "cal_22-mpc_amd", "host")
+CSRC = os.path.join(ROOT, "cal_22-mpc_amd", "csrc")
+NATIVE = os.path.join(ROOT, "tests", "native")
+SAN = ["-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+
+
+def _build(tmp, name, cmd):
+    out = os.path.join(tmp, name)
+    subprocess.run(cmd + ["-o", out], check=True, capture_output=True, text=True)
+    return out
+
+
+def _fnv(data: bytes) -> int:
+    h = 1469598103934665603
+    for b in data:
+        h = ((h ^ b) * 1099511628211) & ((1 << 64) - 1)
+    return h
+
+
+@pytest.fixture(scope="module")
+def loader_probe(tmp_path_factory):
+    tmp = str(tmp_path_factory.mktemp("native"))
+    return _build(tmp, "loader_probe", ["g++", "-std=c++17", *SAN, "-I", HOST, os.path.join(NATIVE, "loader_probe.cpp"),
+                                        os.path.join(HOST, "LoaderNPY.cpp")])
+
+
+@pytest.mark.parametrize("n,L", [(1, 64), (2, 64), (1000, 32), (777, 128)])
+def test_loader_npy_matches_numpy(loader_probe, traces, tmp_path, n, L):
+    lines = traces.structured(n, L, seed=n)
+    p = traces.save_npy(str(tmp_path / "t.npy"), lines)
+    want = _fnv(lines[:-1].tobytes())      # every row but the last (LoaderNPY.cpp:28-32 + main.cpp:240)
+    for mode in (["line"], ["batch", "100"], ["batch", "1"]):
+        r = subprocess.run([loader_probe, p] + mode, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out = r.stdout.strip().split("\n")
+        assert out[0] == f"lines {n} line_size {L}"
+        assert out[1] == f"delivered {n - 1} hash {want}"
+
+
+def test_loader_npy_rejects_bad_files(loader_probe, tmp_path):
+    np.save(str(tmp_path / "f.npy"), np.zeros((4, 64), dtype=np.float32))
+    np.save(str(tmp_path / "d3.npy"), np.zeros((4, 4, 4), dtype=np.uint8))
+    np.save(str(tmp_path / "fo.npy"), np.asfortranarray(np.zeros((4, 64), dtype=np.uint8)))
+    (tmp_path / "junk.npy").write_bytes(b"not an npy file at all")
+    for name in ("f.npy", "d3.npy", "fo.npy", "junk.npy", "missing.npy"):
+        r = subprocess.run([loader_probe, str(tmp_path / name), "line"], capture_output=True, text=True)
+        assert r.returncode == 1 and "Invalid File!" in r.stdout, (name, r.stdout, r.stderr)
+
+
+def test_config_reader_under_sanitizers(tmp_path, configs):
+    probe = _build(str(tmp_path), "config_probe", ["g++", "-std=c++17", *SAN, "-I", CSRC,
+                                                   os.path.join(NATIVE, "config_probe.cpp")])
+    files = []
+    for L in (32, 64, 128):
+        files.append(configs.write_config(configs.probe_config(L), str(tmp_path / f"probe{L}.json")))
+    good = json.dumps(configs.probe_config(64))
+    rng = np.random.default_rng(3)
+    # truncations, byte flips and structural damage: must produce error codes, never a sanitizer report
+    for i in range(120):
+        if i % 3 == 0:
+            bad = good[: int(rng.integers(1, len(good)))]
+        elif i % 3 == 1:
+            b = bytearray(good.encode())
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(32, 127))
+            bad = b.decode(errors="replace")
+        else:
+            cfg = configs.probe_config(64)
+            m = cfg["modules"][str(int(rng.integers(2, 6)))]["submodules"]
+            key = ["ScanModule", "ResidueModule", "XORModule"][int(rng.integers(0, 3))]
+            if key == "ScanModule":
+                m[key]["TableSize"] = int(rng.integers(-5, 2000))
+                m[key]["Rows"] = m[key]["Rows"][: int(rng.integers(0, 512))]
+            elif key == "ResidueModule":
+                m[key]["PredictorModule"]["RootIndex"] = int(rng.integers(-3, 200))
+                m[key]["PredictorModule"].pop("BaseIndexTable", None)
+            else:
+                m[key] = "x"
+            bad = json.dumps(cfg)
+        p = tmp_path / f"bad{i}.json"
+        p.write_text(bad)
+        files.append(str(p))
+    r = subprocess.run([probe] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = r.stdout.strip().split("\n")
+    assert len(out) == len(files)
+    assert all(": rc 0 " in line and "path fast" in line for line in out[:3])
+    assert "cert 30" in out[1]                       # 30 certain 17-bit rows at L = 64 (17*30+7 >= 512)
+    assert sum(": rc -" in line for line in out[3:]) > 60
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    probe = _build(str(tmp_path), "oracle_probe", ["gcc", "-std=c11", *SAN, "-I", os.path.join(ROOT, "oracle"),
+                                                   os.path.join(NATIVE, "oracle_probe.c"),
+                                                   os.path.join(ROOT, "oracle", "mpc_oracle.c"), "-lm"])
+    r = subprocess.run([probe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr[-3000:]
