@@ -179,7 +179,7 @@ __device__ __forceinline__ void module_residue(const LineCtx<LPL> &c, const MpcF
   }
 }
 
-// ---- row-0 prefilter (LPL == 4) ---------------------------------------------
+// ---- row-0 prefilter (LPL == 4 or 8) ----------------------------------------
 // A module other than the last one can only win the selector with at least one
 // leading zero row (ties go to the later module, VPC.cpp:389), i.e. only if the
 // MSBs of residue bytes 0..15 are all clear.  Lane g of a line evaluates word g of
@@ -189,8 +189,8 @@ struct Pre4 {
   u32 t3, t3prev;   // byte 3 of this lane's 4 words / of the previous lane's (ConsecutiveBase)
 };
 
-template <int KIND>
-__device__ __forceinline__ u32 row0_msbs(const LineCtx<4> &c, const Pre4 &p, const MpcFastModule &fm, const WinTab0 &w0)
+template <int LPL, int KIND>
+__device__ __forceinline__ u32 row0_msbs(const LineCtx<LPL> &c, const Pre4 &p, const MpcFastModule &fm, const WinTab0 &w0)
 {
   u32 pred;
   if constexpr (KIND == MPC_FK_ONEBASE) {
@@ -201,7 +201,8 @@ __device__ __forceinline__ u32 row0_msbs(const LineCtx<4> &c, const Pre4 &p, con
     pred = window_predict<KIND>(p.y, p.yprev, w0.sel, w0.c1, w0.c2, fm);
   }
   if (c.g == 0) pred &= 0xffffff00u;       // byte 0 of the residue array is the raw root
-  return bsub(p.y, pred) & H80;
+  const u32 msb = bsub(p.y, pred) & H80;
+  return (LPL > 4 && c.g >= 4) ? 0u : msb;   // column group 0 is spread over lanes 0..3 of the line
 }
 
 // leading zero rows of the scanned array.  The first non-zero row of the XORed
@@ -276,20 +277,30 @@ __device__ __forceinline__ void eval_seq(const LineCtx<LPL> &c, const MpcVpcPara
   if constexpr (Q + 1 < NPT) {
     bool full = true;
     if constexpr (MPC_ABLATE & 8) full = false;
-    if constexpr (LPL == 4 && !(MPC_ABLATE & 8)) {
+    if constexpr (LPL >= 4 && !(MPC_ABLATE & 8)) {
       // prefilter: skip the module when no line of the wave can have a leading zero row
-      const u32 msb = row0_msbs<KIND>(c, pre, P.fm[Q], tabs.w0[Q]);
+      const u32 msb = row0_msbs<LPL, KIND>(c, pre, P.fm[Q], tabs.w0[Q]);
       u64 b = __ballot(msb != 0);
       b |= b >> 1;
-      b |= b >> 2;                                   // bit 4k: some lane of line k has an MSB set
+      b |= b >> 2;                                   // lead lane of a line: some lane 0..3 has an MSB set
       full = (b & need_lines) != need_lines;         // wave-uniform
       if constexpr (MPC_ABLATE & 8) full = false;
     }
     if (full) {
       u32 r[4], root_r;
       module_residue<LPL, KIND>(c, P.fm[Q], tabs.wt[Q], shuf_line, r, root_r);
-      take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), Q, root_r, (u32)P.fm[Q].cx);
-      any_full = true;
+      bool contender = true;
+      if constexpr (LPL == 2 && !(MPC_ABLATE & 8)) {
+        // 32-byte lines: column group 0 is the line's first lane; same row-0 test on the full
+        // residue (saves the fold / leading-zero / update work of a module that cannot win)
+        const u32 msb = (c.g == 0) ? ((r[0] | r[1] | r[2] | r[3]) & H80) : 0u;
+        const u64 b = __ballot(msb != 0);
+        contender = (b & need_lines) != need_lines;
+      }
+      if (contender) {
+        take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), Q, root_r, (u32)P.fm[Q].cx);
+        any_full = true;
+      }
     }
     eval_seq<LPL, NPT, Q + 1, REST...>(c, P, tabs, shuf_line, lut, pre, need_lines, best, any_full);
   } else {
@@ -414,6 +425,7 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
   u32 chunk0 = (blockIdx.x * 4u + wave) * 64u;
   uint4 vnext = make_uint4(0, 0, 0, 0);
   if (chunk0 < n_chunks) vnext = lines[min(chunk0 + lane, n_chunks - 1u)];
+
   for (; chunk0 < n_chunks; chunk0 += stride) {
     // chunk0 is wave-uniform by construction; readfirstlane makes the compiler keep the
     // whole mask algebra below on the scalar unit
@@ -452,23 +464,24 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
       best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
       if constexpr (NPT > 0) {
         Pre4 pre = {0, 0, 0, 0};
-        if constexpr (LPL == 4 && NPT > 1) {
-          // word g of column group 0, and its predecessor
-          const u32 a0 = dpp<QP(0, 0, 0, 0)>(c.x[0]), a1 = dpp<QP(0, 0, 0, 0)>(c.x[1]);
-          const u32 a2 = dpp<QP(0, 0, 0, 0)>(c.x[2]), a3 = dpp<QP(0, 0, 0, 0)>(c.x[3]);
+        if constexpr (LPL >= 4 && NPT > 1) {
+          // word (g & 3) of column group 0 (held by the line's first lane), and its predecessor
+          const u32 a0 = Grp<LPL>::first(c.x[0]), a1 = Grp<LPL>::first(c.x[1]);
+          const u32 a2 = Grp<LPL>::first(c.x[2]), a3 = Grp<LPL>::first(c.x[3]);
           pre.y = (g & 2) ? ((g & 1) ? a3 : a2) : ((g & 1) ? a1 : a0);
           pre.yprev = (g & 2) ? ((g & 1) ? a2 : a1) : a0;
           bool any_consec = false;
 #pragma unroll
           for (int q = 0; q + 1 < NPT; q++) any_consec = any_consec || (kinds[q] == MPC_FK_CONSEC);
           if (any_consec) {
+            // inp[0..15] = byte 3 of words 0..15 = lanes 0..3 of the line (W >= 16)
             const u32 hi01 = perm(c.x[1], c.x[0], 0x07030602u), hi23 = perm(c.x[3], c.x[2], 0x07030602u);
             pre.t3 = perm(hi23, hi01, 0x07060302u);
-            pre.t3prev = Grp<4>::prev(pre.t3);
+            pre.t3prev = Grp<LPL>::prev(pre.t3);
           }
         }
-        eval_seq<LPL, NPT, 0, KINDS...>(c, P, tabs, shuf_line, lut, pre, need_mask & 0x1111111111111111ull, best,
-                                        false);
+        constexpr u64 lead_lanes = LPL == 2 ? 0x5555555555555555ull : (LPL == 4 ? 0x1111111111111111ull : 0x0101010101010101ull);
+        eval_seq<LPL, NPT, 0, KINDS...>(c, P, tabs, shuf_line, lut, pre, need_mask & lead_lanes, best, false);
       } else {
         for (int q = 0; q < n_pred; q++) {
           const MpcFastModule fm = P.fm[q];
@@ -607,6 +620,8 @@ template <int... KINDS>
 static hipError_t launch_seq(const uint4 *l, u32 n_chunks, u64 first_line, const MpcVpcParams *P, uint16_t *d_sizes,
                              int8_t *d_sel, u64 *d_stats, int grid, size_t smem, hipStream_t stream)
 {
+  // persistent grid-stride kernel: `grid` (8 workgroups per CU, capped by the work) was A/B-tested
+  // against occupancy-sized grids on one box: no measurable difference, so the simple rule stays
   switch (P->L) {
   case 32: hipLaunchKernelGGL((vpc_fast_kernel<2, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_chunks, first_line, *P, d_sizes, d_sel, d_stats); break;
   case 64: hipLaunchKernelGGL((vpc_fast_kernel<4, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_chunks, first_line, *P, d_sizes, d_sel, d_stats); break;
