@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -310,7 +311,12 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     if (m.pred_kind == PRED_DIFF) {
       f.kind = MPC_FK_DIFF;
     } else {
-      f.kind = MPC_FK_WEIGHT;
+      // put an unshifted class first: the kernel then skips its two shift instructions
+      if (nshift == 2 && shifts[0] != 0 && shifts[1] == 0) {
+        std::swap(shifts[0], shifts[1]);
+        std::swap(c1, c2);
+      }
+      f.kind = (shifts[0] == 0) ? MPC_FK_WEIGHT : MPC_FK_WEIGHT2;
       f.ls1 = shifts[0] > 0 ? shifts[0] : 0;
       f.rs1 = shifts[0] < 0 ? -shifts[0] : 0;
       f.ls2 = shifts[1] > 0 ? shifts[1] : 0;

@@ -14,7 +14,9 @@ enum {
   MPC_FK_ONEBASE = 0,  /* every byte predicted by byte 0                         */
   MPC_FK_CONSEC  = 1,  /* previous byte of the byte-plane-shuffled line          */
   MPC_FK_DIFF    = 2,  /* base byte in own/previous dword (v_perm) + constant     */
-  MPC_FK_WEIGHT  = 3   /* base byte in own/previous dword (v_perm), <=2 shifts    */
+  MPC_FK_WEIGHT  = 3,  /* base byte in own/previous dword (v_perm); shift class 1 is the
+                          unshifted one (ls1 = rs1 = 0), class 2 any single shift           */
+  MPC_FK_WEIGHT2 = 4   /* same with two shifted classes                                   */
 };
 
 struct MpcFastModule {

@@ -116,6 +116,8 @@ __device__ __forceinline__ u32 window_predict(u32 own, u32 prevw, u32 sel, u32 c
   const u32 b = perm(own, prevw, sel);
   if constexpr (KIND == MPC_FK_DIFF)
     return badd(b, c1);
+  else if constexpr (KIND == MPC_FK_WEIGHT)      // class 1 unshifted (a shift by 0 is a real instruction)
+    return (b & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
   else
     return (((b << fm.ls1) >> fm.rs1) & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
 }
@@ -409,7 +411,7 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
   if constexpr (NPT > 0) {
 #pragma unroll
     for (int q = 0; q < NPT; q++) {
-      if (kinds[q] == MPC_FK_DIFF || kinds[q] == MPC_FK_WEIGHT) {
+      if (kinds[q] == MPC_FK_DIFF || kinds[q] == MPC_FK_WEIGHT || kinds[q] == MPC_FK_WEIGHT2) {
         load_wintab(P.tab, P.fm[q], W, g, tabs.wt[q]);
         const u32 *t = P.tab + P.fm[q].tab_off;     // column group 0, word g (row-0 prefilter)
         tabs.w0[q].sel = t[g & 3];
@@ -495,7 +497,8 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
           case MPC_FK_ONEBASE: eval_update<LPL, MPC_FK_ONEBASE>(c, fm, w, shuf_line, lut, q, best); break;
           case MPC_FK_CONSEC: eval_update<LPL, MPC_FK_CONSEC>(c, fm, w, shuf_line, lut, q, best); break;
           case MPC_FK_DIFF: load_wintab(P.tab, fm, W, g, w); eval_update<LPL, MPC_FK_DIFF>(c, fm, w, shuf_line, lut, q, best); break;
-          default: load_wintab(P.tab, fm, W, g, w); eval_update<LPL, MPC_FK_WEIGHT>(c, fm, w, shuf_line, lut, q, best); break;
+          case MPC_FK_WEIGHT: load_wintab(P.tab, fm, W, g, w); eval_update<LPL, MPC_FK_WEIGHT>(c, fm, w, shuf_line, lut, q, best); break;
+          default: load_wintab(P.tab, fm, W, g, w); eval_update<LPL, MPC_FK_WEIGHT2>(c, fm, w, shuf_line, lut, q, best); break;
           }
         }
       }

@@ -89,12 +89,14 @@ def test_vpc_fast_path_variants(mpc, oracle, configs, traces):
     w3 = [[1.0, 0.5, 1.0, 1.0][i % 4] for i in range(L)]
     w_up = [[2.0, 1.0][i % 2] for i in range(L)]
     w_big = [[256.0, 0.001][i % 2] for i in range(L)]     # shifts >= 8 / <= -8 clear the byte
+    w_two = [[2.0, 0.5][i % 2] for i in range(L)]         # two shifted classes (no unshifted one)
     cfg = configs.make_config(L, [{"name": "AllZero"}, {"name": "ByteplaneAllSame"},
                                   configs.diff_base(L, base1, diff, 0, True),
                                   configs.diff_base(L, base2, [0] * L, 0, False),
                                   configs.weight_base(L, base_inword, w3, 0, True),
                                   configs.weight_base(L, base1, w_up, 0, False),
-                                  configs.weight_base(L, base2, w_big, 0, True)])
+                                  configs.weight_base(L, base2, w_big, 0, True),
+                                  configs.weight_base(L, base1, w_two, 0, False)])
     _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
     # a single prediction module, and none at all
     cfg = configs.make_config(L, [{"name": "AllZero"}, {"name": "AllWordSame"}, configs.consecutive_base(L)])
