@@ -310,13 +310,19 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     if (!plan.fast) break;
     if (m.pred_kind == PRED_DIFF) {
       f.kind = MPC_FK_DIFF;
+      // the kernel adds the constant as ((b & 0x7f..) + c1) ^ ((b & 0x80..) ^ c2)
+      for (size_t w = 0; w < c1.size(); w++) {
+        c2[w] = c1[w] & 0x80808080u;
+        c1[w] = c1[w] & 0x7f7f7f7fu;
+      }
     } else {
       // put an unshifted class first: the kernel then skips its two shift instructions
       if (nshift == 2 && shifts[0] != 0 && shifts[1] == 0) {
         std::swap(shifts[0], shifts[1]);
         std::swap(c1, c2);
       }
-      f.kind = (shifts[0] == 0) ? MPC_FK_WEIGHT : MPC_FK_WEIGHT2;
+      // MPC_FK_WEIGHT: class 1 unshifted, class 2 a right shift (or absent); anything else is WEIGHT2
+      f.kind = (shifts[0] == 0 && shifts[1] <= 0) ? MPC_FK_WEIGHT : MPC_FK_WEIGHT2;
       f.ls1 = shifts[0] > 0 ? shifts[0] : 0;
       f.rs1 = shifts[0] < 0 ? -shifts[0] : 0;
       f.ls2 = shifts[1] > 0 ? shifts[1] : 0;

@@ -85,6 +85,7 @@ struct LineCtx {
   u32 rootb;   // root replicated into 4 bytes
   u32 xm1;     // previous lane's last word (garbage for g == 0, never selected)
   u32 g;
+  u32 cm0;     // 0xffffff00 on the lane that holds column 0 (the root), else 0xffffffff
 };
 
 // 4x4 transpose of 32-bit words across the 4 lanes of a quad: out lane g, slot e
@@ -115,9 +116,9 @@ __device__ __forceinline__ u32 window_predict(u32 own, u32 prevw, u32 sel, u32 c
 {
   const u32 b = perm(own, prevw, sel);
   if constexpr (KIND == MPC_FK_DIFF)
-    return badd(b, c1);
-  else if constexpr (KIND == MPC_FK_WEIGHT)      // class 1 unshifted (a shift by 0 is a real instruction)
-    return (b & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
+    return ((b & L7F) + c1) ^ ((b & H80) ^ c2);   // per-byte b + diff; the host split diff into c1 = low 7 bits, c2 = MSBs
+  else if constexpr (KIND == MPC_FK_WEIGHT)      // class 1 unshifted, class 2 shifted right (weights <= 1)
+    return (b & c1) | ((b >> fm.rs2) & c2);
   else
     return (((b << fm.ls1) >> fm.rs1) & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
 }
@@ -134,7 +135,7 @@ __device__ __forceinline__ void module_residue(const LineCtx<LPL> &c, const MpcF
     // predicted = line[0] everywhere; position 0 of the residue array is the raw root
 #pragma unroll
     for (int e = 0; e < 4; e++) r[e] = bsub(c.x[e], c.rootb);
-    if (c.g == 0) r[0] = (r[0] & 0xffffff00u) | c.b0;
+    r[0] = (r[0] & c.cm0) | (c.b0 & ~c.cm0);     // position 0 of the residue array is the raw root
   } else if constexpr (KIND == MPC_FK_CONSEC) {
     // inp = bytes reordered plane 3,2,1,0 of each word; predicted[i] = inp[i-1].
     // 4x4 byte transpose of this lane's words: T[k] = byte k of the 4 words
@@ -166,8 +167,7 @@ __device__ __forceinline__ void module_residue(const LineCtx<LPL> &c, const MpcF
       __builtin_amdgcn_wave_barrier();
     }
     const u32 carry = Grp<LPL>::prev(in[3]);     // inp[16g-1]: last byte of the previous lane
-    u32 p0 = alignbyte(in[0], carry, 3);
-    if (c.g == 0) p0 &= 0xffffff00u;            // root: predicted byte 0 -> residue[0] = raw root
+    const u32 p0 = alignbyte(in[0], carry, 3) & c.cm0;   // root: predicted byte 0 -> residue[0] = raw root
     r[0] = bsub(c.x[0], p0);
     r[1] = bsub(c.x[1], alignbyte(in[1], in[0], 3));
     r[2] = bsub(c.x[2], alignbyte(in[2], in[1], 3));
@@ -205,7 +205,7 @@ __device__ __forceinline__ u32 row0_msbs(const LineCtx<LPL> &c, const Pre4 &p, c
   } else {
     pred = window_predict<KIND>(p.y, p.yprev, w0.sel, w0.c1, w0.c2, fm);
   }
-  if (c.g == 0) pred &= 0xffffff00u;       // byte 0 of the residue array is the raw root
+  pred &= c.cm0;                           // byte 0 of the residue array is the raw root
   const u32 msb = bsub(p.y, pred) & H80;
   return (LPL > 4 && c.g >= 4) ? 0u : msb;   // column group 0 is spread over lanes 0..3 of the line
 }
@@ -303,7 +303,17 @@ __device__ __forceinline__ void eval_seq(const LineCtx<LPL> &c, const MpcVpcPara
         contender = (b & need_lines) != need_lines;
       }
       if (contender) {
-        take_if_better<LPL>(best, r, leading_zero_rows<LPL>(r, c.g, lut), Q, root_r, (u32)P.fm[Q].cx);
+        const u32 z = leading_zero_rows<LPL>(r, c.g, lut);
+        if (any_full) {
+          take_if_better<LPL>(best, r, z, Q, root_r, (u32)P.fm[Q].cx);
+        } else {   // first candidate of this wave: plain assignment (best is not initialised before)
+          best.z = z;
+          best.q = Q;
+          best.root_r = root_r;
+          best.cx = (u32)P.fm[Q].cx;
+#pragma unroll
+          for (int e = 0; e < 4; e++) best.r[e] = r[e];
+        }
         any_full = true;
       }
     }
@@ -443,6 +453,7 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
     LineCtx<LPL> c;
     c.x[0] = v.x; c.x[1] = v.y; c.x[2] = v.z; c.x[3] = v.w;
     c.g = g;
+    c.cm0 = colmask0;
 
     // ---- AllZero / AllWordSame: per-line predicates as lane masks, on the scalar unit ----
     c.w0 = Grp<LPL>::first(c.x[0]);
@@ -467,8 +478,10 @@ vpc_fast_kernel(const uint4 *__restrict__ lines, u32 n_chunks, u64 first_line, M
       c.rootb = perm(c.w0, c.w0, 0u);            // byte 0 replicated
       c.xm1 = Grp<LPL>::prev(c.x[3]);
       Winner best;
-      best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
-      best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
+      if constexpr (NPT == 0) {
+        best.r[0] = best.r[1] = best.r[2] = best.r[3] = 0;
+        best.z = 0; best.q = -1; best.root_r = 0; best.cx = 0;
+      }
       if constexpr (NPT > 0) {
         Pre4 pre = {0, 0, 0, 0};
         if constexpr (LPL >= 4 && NPT > 1) {
