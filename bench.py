@@ -41,7 +41,7 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0):
+def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0, algo: str = "VPC"):
     """The oracle (a CPU port of the reference algorithm, NOT the product path) timed on
     this host's cores over a bounded sample of the same workload."""
     from oracle import oracle as O
@@ -50,16 +50,17 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0):
            "zeros": traces.zeros, "pointers_u64": traces.pointers_u64}[kind]
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     cfg = configs.probe_config(L)
+    make = (lambda: O.VpcOracle(cfg)) if algo == "VPC" else (lambda: O.BdiOracle(L))
     # calibrate on a short run, then size the sample for ~`seconds` of wall time
     cal_n = 4096
     cal = gen(cal_n, L)
-    o = O.VpcOracle(cfg)
+    o = make()
     t0 = time.perf_counter()
     o.compress(cal, stats=True)
     rate1 = cal_n / (time.perf_counter() - t0)
     per_thread = int(min(max(rate1 * seconds, 4096), 4 << 20))
     data = gen(per_thread, L)
-    oracles = [O.VpcOracle(cfg) for _ in range(cores)]
+    oracles = [make() for _ in range(cores)]
     ths = [threading.Thread(target=oracles[i].compress, args=(data,)) for i in range(cores)]  # ctypes drops the GIL
     t0 = time.perf_counter()
     for t in ths:
@@ -69,7 +70,7 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0):
     dt = time.perf_counter() - t0
     return {"value": cores * per_thread / dt, "unit": "blocks/s", "cores": cores, "kind": "port",
             "sample": f"{per_thread} {workload} {L} B blocks per thread x {cores} threads "
-                      f"(oracle/mpc_oracle.c, probe config), {dt:.1f} s",
+                      f"(oracle/mpc_oracle.c, {'probe config' if algo == 'VPC' else 'BDI'}), {dt:.1f} s",
             "single_core_blocks_per_s": rate1}
 
 
@@ -219,7 +220,7 @@ def main():
                          "read_probe_gbps": probe_gbps, "frac_of_read_probe": achieved / probe_gbps},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(configs, traces, args.workload, L)
+            out["cpu_baseline"] = cpu_baseline(configs, traces, args.workload, L, algo=args.algo)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
