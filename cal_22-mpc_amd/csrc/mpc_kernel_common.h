@@ -94,6 +94,62 @@ __device__ __forceinline__ u32 sum_bytes(u32 x, u32 acc) { return __builtin_amdg
 __device__ __forceinline__ u32 sum_sq_bytes(u32 x, u32 acc) { return __builtin_amdgcn_udot4(x, x, acc, false); }
 
 // ---------------------------------------------------------------------------
+// common encoder on 8 rows of one 16-column group (bit j <-> plane 7-j).  t[4] = transformed
+// residue bytes of the group's 16 columns.  Returns the bits of the non-zero rows.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 encode_rows(const u32 t[4], u32 &zero_mask)
+{
+  // per plane: S = any bit set, T = set in >= 2 columns, U = in >= 3 columns
+  u32 s01 = t[0] | t[1], t01 = t[0] & t[1];
+  u32 s23 = t[2] | t[3], t23 = t[2] & t[3];
+  u32 S = s01 | s23;
+  u32 T = t01 | t23 | (s01 & s23);
+  u32 U = (t01 & s23) | (s01 & t23);
+  {   // fold the 4 byte lanes: counts add up across bytes
+    u32 S2 = S >> 16, T2 = T >> 16, U2 = U >> 16;
+    u32 nU = U | U2 | (T & S2) | (S & T2);
+    u32 nT = T | T2 | (S & S2);
+    S |= S2; T = nT; U = nU;
+  }
+  {
+    u32 S2 = S >> 8, T2 = T >> 8, U2 = U >> 8;
+    u32 nU = U | U2 | (T & S2) | (S & T2);
+    u32 nT = T | T2 | (S & S2);
+    S |= S2; T = nT; U = nU;
+  }
+  S &= 0xffu; T &= 0xffu; U &= 0xffu;
+  const u32 Sf = fold8(s01);   // columns 0..7
+  const u32 Sb = fold8(s23);   // columns 8..15
+  // two ones in adjacent columns c, c+1 (c = 0..14)
+  u32 A = (t[0] & alignbyte(t[1], t[0], 1)) | (t[1] & alignbyte(t[2], t[1], 1)) |
+          (t[2] & alignbyte(t[3], t[2], 1)) | (t[3] & (t[3] >> 8));
+  A = fold8(A);
+  const u32 single = S & ~T;             // exactly one 1: 7 bits
+  const u32 two = T & ~U & A;            // exactly two, adjacent: 8 bits
+  const u32 rest = S & ~single & ~two;
+  const u32 both = Sf & Sb;
+  const u32 half = rest & ~both;         // one 8-column half empty: 12 bits
+  const u32 full = rest & both;          // 17 bits
+  zero_mask = ~S & 0xffu;
+  return 7u * __popc(single) + 8u * __popc(two) + 12u * __popc(half) + 17u * __popc(full);
+}
+
+// predicted word from the own / previous word (v_perm) + diff constant or per-byte shifts.
+// (Specialising the usual "one unshifted class + one single-direction shift" WeightBase tables
+// behind a wave-uniform branch was A/B-tested on one box and was slower: not done.)
+template <int KIND>
+__device__ __forceinline__ u32 window_predict(u32 own, u32 prevw, u32 sel, u32 c1, u32 c2, const MpcFastModule &fm)
+{
+  const u32 b = perm(own, prevw, sel);
+  if constexpr (KIND == MPC_FK_DIFF)
+    return ((b & L7F) + c1) ^ ((b & H80) ^ c2);   // per-byte b + diff; the host split diff into c1 = low 7 bits, c2 = MSBs
+  else if constexpr (KIND == MPC_FK_WEIGHT)      // class 1 unshifted, class 2 shifted right (weights <= 1)
+    return (b & c1) | ((b >> fm.rs2) & c2);
+  else
+    return (((b << fm.ls1) >> fm.rs1) & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
+}
+
+// ---------------------------------------------------------------------------
 // statistics: per-workgroup LDS accumulators, flushed once per workgroup
 // ---------------------------------------------------------------------------
 struct WgStats {

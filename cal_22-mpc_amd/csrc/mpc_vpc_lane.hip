@@ -1,0 +1,457 @@
+// mpc_vpc_lane.hip -- VPC multi-prediction evaluation, one LANE per line (32 / 64 byte
+// lines of fast-path configurations, see mpc_config.h: build_vpc_plan).  gfx950 / wave64.
+//
+// Mapping: lane i of a wave holds the whole line (line0 + i) in W = L/4 registers,
+// fetched with L/16 global_load_dwordx4 (the four loads of a wave cover one contiguous
+// 64*L byte span, so every fetched cache line is fully used).  Nothing crosses lanes:
+// the per-line predicates are per-lane booleans, a __ballot of one gives the
+// wave-uniform decisions (skip the prediction modules of an all-zero wave, skip a
+// module that cannot win anywhere in the wave, skip the encoder when every line is
+// certified incompressible).  Against the 4-lanes-per-line kernel (mpc_vpc_fast.hip)
+// the byte work per line is the same SWAR arithmetic, but everything that is per
+// line -- masks, selector, winner bookkeeping, statistics, loop control -- is issued
+// once per 64 lines instead of once per 16, and the kernel is issue-bound.
+//
+// Stages against the reference (src/compressor/...): see the header of
+// mpc_vpc_fast.hip; the arithmetic identities (XOR stage on bytes, selector on raw
+// residues, row-0 prefilter, incompressibility certificate) are the same.
+#include "mpc_kernel_common.h"
+
+namespace {
+
+template <int W>
+struct Lane {
+  u32 x[W];    // the line
+  u32 b0;      // byte 0 = root (RootIndex 0)
+  u32 rootb;   // root replicated into 4 bytes
+};
+
+// bit 7 of every byte = MSB of the per-byte difference a - b (the other bits are junk)
+__device__ __forceinline__ u32 msb_of_bsub(u32 a, u32 b) { return ((a | H80) - (b & L7F)) ^ a ^ ~b; }
+
+// byte k of the four words x[4q..4q+3] (one row of their 4x4 byte transpose)
+template <int W>
+__device__ __forceinline__ u32 plane_bytes(const u32 (&x)[W], int q, int k)
+{
+  const u32 s01 = k >= 2 ? 0x07030602u : 0x05010400u;
+  const u32 p01 = perm(x[4 * q + 1], x[4 * q], s01), p23 = perm(x[4 * q + 3], x[4 * q + 2], s01);
+  return perm(p23, p01, (k & 1) ? 0x07060302u : 0x05040100u);
+}
+
+// dword j of the byte-plane-shuffled line `inp` (PredictorModule.cpp:143-155):
+// inp[n] = byte (3 - n / W) of word n % W
+template <int W>
+__device__ __forceinline__ u32 shuffled_word(const u32 (&x)[W], int j)
+{
+  constexpr int NG = W / 4;
+  return plane_bytes<W>(x, j % NG, 3 - j / NG);
+}
+
+// Residue bytes (root first == natural order for RootIndex 0) of one module;
+// root_r = the residue GetMAE / GetMSE see at the root position.
+template <int W, int KIND>
+__device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModule &fm, const u32 *__restrict__ tab,
+                                             u32 (&r)[W], u32 &root_r)
+{
+  root_r = 0;
+  if constexpr (KIND == MPC_FK_ONEBASE) {
+    // predicted = line[0] everywhere; position 0 of the residue array is the raw root
+    r[0] = bsub(c.x[0], c.rootb & 0xffffff00u);
+#pragma unroll
+    for (int e = 1; e < W; e++) r[e] = bsub(c.x[e], c.rootb);
+  } else if constexpr (KIND == MPC_FK_CONSEC) {
+    // predicted[i] = inp[i - 1]; predicted byte 0 := 0 keeps the raw root at position 0
+    u32 in[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) in[j] = shuffled_word<W>(c.x, j);
+    r[0] = bsub(c.x[0], in[0] << 8);
+#pragma unroll
+    for (int e = 1; e < W; e++) r[e] = bsub(c.x[e], alignbyte(in[e], in[e - 1], 3));
+    // predicted[root] = inp[0] = byte 3 of word 0 (PredictorModule.cpp:159-164)
+    root_r = (c.b0 - (c.x[0] >> 24)) & 0xffu;
+  } else {
+    // windowed tables; they force the predicted root byte to 0, so residue[0] = raw root
+    const u32 *t = tab + fm.tab_off;
+#pragma unroll
+    for (int e = 0; e < W; e++)
+      r[e] = bsub(c.x[e], window_predict<KIND>(c.x[e], e ? c.x[e - 1] : 0u, t[e], t[W + e], t[2 * W + e], fm));
+  }
+}
+
+// Row-0 prefilter: a module other than the last one can only win the selector with at
+// least one leading zero row (ties go to the later module, VPC.cpp:389), i.e. only if
+// the MSBs of residue bytes 0..15 are all clear.  Returns those MSBs ORed together.
+template <int W, int KIND>
+__device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &fm, const u32 *__restrict__ tab)
+{
+  u32 m;
+  if constexpr (KIND == MPC_FK_ONEBASE) {
+    m = msb_of_bsub(c.x[0], c.rootb & 0xffffff00u);
+#pragma unroll
+    for (int e = 1; e < 4; e++) m |= msb_of_bsub(c.x[e], c.rootb);
+  } else if constexpr (KIND == MPC_FK_CONSEC) {
+    u32 in[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) in[j] = shuffled_word<W>(c.x, j);
+    m = msb_of_bsub(c.x[0], in[0] << 8);
+#pragma unroll
+    for (int e = 1; e < 4; e++) m |= msb_of_bsub(c.x[e], alignbyte(in[e], in[e - 1], 3));
+  } else {
+    const u32 *t = tab + fm.tab_off;
+    m = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      m |= msb_of_bsub(c.x[e], window_predict<KIND>(c.x[e], e ? c.x[e - 1] : 0u, t[e], t[W + e], t[2 * W + e], fm));
+  }
+  return m & H80;
+}
+
+// Leading zero rows of the scanned array (row = plane * W/4 + column group).  The first
+// non-zero row of the XORed planes equals that of the raw residue planes (DESIGN.md
+// "Selector on raw residues"), so the selector works on r directly.
+template <int W>
+__device__ __forceinline__ u32 lane_leading_zero_rows(const u32 (&r)[W])
+{
+  constexpr int NG = W / 4;
+  u32 S[NG], G = 0;
+#pragma unroll
+  for (int j = 0; j < NG; j++) {
+    S[j] = r[4 * j] | r[4 * j + 1] | r[4 * j + 2] | r[4 * j + 3];
+    G |= S[j];
+  }
+  const u32 p = (u32)__clz((int)fold8(G)) - 24u;     // first non-zero plane (0 = MSB); 8 if G == 0
+  const u32 B = H80 >> (p & 7u);                      // that plane's bit in every byte
+  u32 j_star = NG - 1;
+#pragma unroll
+  for (int j = NG - 2; j >= 0; j--) j_star = (S[j] & B) ? (u32)j : j_star;
+  return G ? NG * p + j_star : 2u * W;
+}
+
+template <int W>
+struct LaneBest {
+  u32 r[W];
+  u32 z;
+  int q;
+  u32 root_r;
+  u32 cx;
+};
+
+template <int W, int NPT, int Q>
+__device__ __forceinline__ void lane_seq(const Lane<W> &, const MpcVpcParams &, u64, LaneBest<W> &, bool) {}
+
+// modules in order; a module that the wave-uniform row-0 prefilter rules out everywhere is skipped
+template <int W, int NPT, int Q, int KIND, int... REST>
+__device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P, u64 need_mask, LaneBest<W> &best,
+                                         bool any_full)
+{
+  const bool last = Q + 1 == NPT;
+  bool full = true;
+  if constexpr (!last) {
+    const u32 msb = lane_row0<W, KIND>(c, P.fm[Q], P.tab);
+    full = (__ballot(msb != 0) & need_mask) != need_mask;    // some needed line has a clear row 0
+  }
+  if (full) {
+    u32 r[W], root_r;
+    lane_residue<W, KIND>(c, P.fm[Q], P.tab, r, root_r);
+    if (any_full) {
+      const u32 z = lane_leading_zero_rows<W>(r);
+      const bool take = best.z <= z;     // ties go to the later module (VPC.cpp:389)
+      best.z = take ? z : best.z;
+      best.q = take ? Q : best.q;
+      best.root_r = take ? root_r : best.root_r;
+      best.cx = take ? (u32)P.fm[Q].cx : best.cx;
+#pragma unroll
+      for (int e = 0; e < W; e++) best.r[e] = take ? r[e] : best.r[e];
+    } else {
+      // first candidate of this wave (best is not initialised before); the last module's z
+      // only matters against an earlier candidate
+      if constexpr (!last) best.z = lane_leading_zero_rows<W>(r);
+      best.q = Q;
+      best.root_r = root_r;
+      best.cx = (u32)P.fm[Q].cx;
+#pragma unroll
+      for (int e = 0; e < W; e++) best.r[e] = r[e];
+    }
+    any_full = true;
+  }
+  if constexpr (!last) lane_seq<W, NPT, Q + 1, REST...>(c, P, need_mask, best, any_full);
+}
+
+// common encoder (FPCModule.cpp:19-85) over all rows of the line: non-zero rows by
+// pattern, zero rows as runs in row order (plane-major, then column group)
+template <int W>
+__device__ __forceinline__ u32 lane_encode(const u32 (&t)[W])
+{
+  constexpr int NG = W / 4;
+  u32 bits = 0, ZP = 0;     // byte j of ZP: zero-row mask of column group j (bit 7-p = plane p)
+#pragma unroll
+  for (int j = 0; j < NG; j++) {
+    u32 Z;
+    bits += encode_rows(&t[4 * j], Z);
+    ZP |= Z << (8 * j);
+  }
+  // previous row of (p, j): (p, j-1), or (p-1, NG-1) for j = 0; next row: (p, j+1), or (p+1, 0)
+  constexpr u32 all = NG == 4 ? 0xffffffffu : ((1u << (8 * NG)) - 1u);
+  const u32 prevP = ((ZP << 8) & all) | (ZP >> (8 * (NG - 1) + 1));
+  const u32 nextP = (ZP >> 8) | ((ZP & 0x7fu) << (8 * (NG - 1) + 1));
+  const u32 starts = ZP & ~prevP;
+  return bits + 4u * __popc(starts) + 3u * __popc(starts & nextP);   // 4 bits per run, 7 if longer than one row
+}
+
+// Run-length statistics per lane: consecutive lines of a lane with the same
+// (cluster, size) key only touch registers.
+struct LaneRun {
+  u32 key;     // (cluster + 1) << 16 | size
+  u32 cnt;
+  u32 acc_r, acc_r2;
+};
+
+__device__ __forceinline__ void lane_run_flush(const LaneRun &rs, const WgStats &st, int K, int bins)
+{
+  if (rs.cnt) {
+    const int k = (int)(rs.key >> 16);
+    atomicAdd(&st.hist[k * bins + (int)(rs.key & 0xffffu)], rs.cnt);
+    if (rs.acc_r | rs.acc_r2) {
+      atomicAdd(&st.sums[k], (u64)rs.acc_r);
+      atomicAdd(&st.sums[K + k], (u64)rs.acc_r2);
+    }
+  }
+}
+
+// n_lines < 2^31 per launch (the host splits larger batches)
+template <int W, bool OUT, int... KINDS>
+__global__ void __launch_bounds__(256)
+vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
+                uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int L = 4 * W;
+  constexpr int NQ = W / 4;             // 16-byte pieces per line
+  constexpr int NPT = sizeof...(KINDS);
+  const int K = P.M + 1, bins = P.hist_bins;
+  WgStats st;
+  st.sums = reinterpret_cast<u64 *>(smem);
+  st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * K * 8 + 15) / 16));
+  stats_init(st, K, bins);   // ends with __syncthreads()
+
+  const u32 lane = threadIdx.x & 63;
+  const u32 uncomp = 8u * L;
+  const u32 enc_zero = (u32)P.enc_bits[1], enc_same = 32u + (u32)P.enc_bits[2], enc_unc = (u32)P.enc_bits[0];
+  const u32 cert_min = (u32)P.cert_min17;
+
+  LaneRun rs = {0xffffffffu, 0, 0, 0};
+  u32 iter = 0;
+
+  // wave-uniform first line of the wave's group of 64: the address math stays on the scalar unit
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 stride = gridDim.x * 256u;
+  u32 line0 = (blockIdx.x * 4u + wave) * 64u;
+  uint4 vnext[NQ];
+  if (line0 < n_lines) {
+    const uint4 *src = lines + (u64)min(line0 + lane, n_lines - 1u) * NQ;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) vnext[i] = src[i];
+  }
+
+  for (; line0 < n_lines; line0 += stride) {
+    const bool valid = line0 + lane < n_lines;
+    Lane<W> c;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+      c.x[4 * i] = vnext[i].x; c.x[4 * i + 1] = vnext[i].y; c.x[4 * i + 2] = vnext[i].z; c.x[4 * i + 3] = vnext[i].w;
+    }
+    {
+      // prefetch the next iteration (clamped: past the end it re-reads the last line)
+      const uint4 *src = lines + (u64)min(line0 + stride + lane, n_lines - 1u) * NQ;
+#pragma unroll
+      for (int i = 0; i < NQ; i++) vnext[i] = src[i];
+    }
+
+    // ---- AllZero / AllWordSame (VPC.cpp:332-364) ----
+    u32 diff = 0;
+#pragma unroll
+    for (int e = 1; e < W; e++) diff |= c.x[e] ^ c.x[0];
+    const bool is_rep = diff == 0;                       // every word equals word 0
+    const bool is_zero = (diff | c.x[0]) == 0;
+    const bool need = valid && !(is_zero || (P.has_aws && is_rep));
+    const u64 need_mask = __ballot(need);
+
+    int chosen = is_zero ? 0 : 1;
+    u32 size = is_zero ? enc_zero : enc_same;
+    u32 sum_r = 0, sum_r2 = 0;        // residue statistics of this line (VPC.cpp:417-443)
+
+    if (need_mask) {     // wave-uniform: some line needs the prediction modules
+      c.b0 = c.x[0] & 0xffu;
+      c.rootb = perm(c.x[0], c.x[0], 0u);
+      LaneBest<W> best;
+      lane_seq<W, NPT, 0, KINDS...>(c, P, need_mask, best, false);
+
+      // XOR stage of the winner, on bytes: b ^ (b >> 1), or b ^ 0x7f where the MSB is set;
+      // column 0 untouched.  The flavour is usually the same for the whole wave.
+      u32 t[W];
+      const u64 cx_mask = __ballot(best.cx != 0);
+      if ((cx_mask & need_mask) == need_mask) {
+#pragma unroll
+        for (int e = 0; e < W; e++) {
+          const u32 f = (best.r[e] >> 1) & (e == 0 ? 0x7f7f7f00u : L7F);
+          t[e] = best.r[e] ^ f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < W; e++) {
+          const u32 m = (best.r[e] >> 7) & 0x01010101u;
+          const u32 f = best.cx ? ((best.r[e] >> 1) & L7F) : ((m << 7) - m);
+          t[e] = best.r[e] ^ (e == 0 ? (f & 0xffffff00u) : f);
+        }
+      }
+      // Incompressibility certificate: a row whose two 8-column halves are both non-zero
+      // and that has a bit outside columns 7/8 costs 17 bits (it is neither a single one
+      // nor an adjacent pair).  With cert_min17 such rows the line cannot beat 8*L bits.
+      u32 n17 = 0;
+#pragma unroll
+      for (int j = 0; j < NQ; j++) {
+        const u32 Sf = fold8(t[4 * j] | t[4 * j + 1]), Sb = fold8(t[4 * j + 2] | t[4 * j + 3]);
+        const u32 So = fold8(t[4 * j] | (t[4 * j + 1] & 0x00ffffffu) | (t[4 * j + 2] & 0xffffff00u) | t[4 * j + 3]);
+        n17 += (u32)__popc(Sf & Sb & So);
+      }
+      const bool open = need && n17 < cert_min;
+      u32 enc = uncomp;
+      if (__ballot(open)) enc = lane_encode<W>(t);
+      const bool keep = open && enc < uncomp;             // VPC.cpp:397-407
+      const u64 keep_mask = __ballot(keep);
+
+      // residue statistics over all positions: the winner's residues (the root position
+      // holds best.root_r, not the raw root), or the raw bytes when the line stays
+      // uncompressed; nothing for AllZero / AllWordSame lines (VPC.cpp:412 is not reached)
+      if (keep_mask == 0) {
+#pragma unroll
+        for (int e = 0; e < W; e++) {
+          sum_r = sum_bytes(c.x[e], sum_r);
+          sum_r2 = sum_sq_bytes(c.x[e], sum_r2);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < W; e++) {
+          u32 v = keep ? best.r[e] : c.x[e];
+          if (e == 0) v = keep ? ((v & 0xffffff00u) | best.root_r) : v;
+          sum_r = sum_bytes(v, sum_r);
+          sum_r2 = sum_sq_bytes(v, sum_r2);
+        }
+      }
+      sum_r = need ? sum_r : 0u;
+      sum_r2 = need ? sum_r2 : 0u;
+      if (need) {
+        chosen = keep ? P.start + best.q : -1;
+        size = keep ? enc + (u32)P.enc_bits[chosen + 1] : uncomp + enc_unc;
+      }
+    }
+
+    // ---- statistics: run-length per lane ----
+    const u32 key = ((u32)(chosen + 1) << 16) | size;
+    if (valid) {
+      if (key != rs.key) {
+        lane_run_flush(rs, st, K, bins);
+        rs.key = key;
+        rs.cnt = 0;
+        rs.acc_r = 0;
+        rs.acc_r2 = 0;
+      }
+      rs.cnt++;
+      rs.acc_r += sum_r;
+      rs.acc_r2 += sum_r2;
+    }
+    if ((++iter & 255u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
+      lane_run_flush(rs, st, K, bins);
+      rs.cnt = 0;
+      rs.acc_r = 0;
+      rs.acc_r2 = 0;
+    }
+
+    // ---- per-line outputs (parity mode) ----
+    if constexpr (OUT) {
+      if (valid) {
+        const u64 line = first_line + line0 + lane;
+        if (sizes_out) sizes_out[line] = (uint16_t)size;
+        if (sel_out) sel_out[line] = (int8_t)chosen;
+      }
+    }
+  }
+  lane_run_flush(rs, st, K, bins);
+  stats_flush(st, K, bins, gstats);
+}
+
+#define OB MPC_FK_ONEBASE
+#define CS MPC_FK_CONSEC
+#define DF MPC_FK_DIFF
+#define WT MPC_FK_WEIGHT
+
+template <int... KINDS>
+bool lane_seq_matches(const MpcVpcParams *P)
+{
+  constexpr int n = sizeof...(KINDS);
+  const int kinds[n] = {KINDS...};
+  if (P->n_pred != n) return false;
+  for (int q = 0; q < n; q++)
+    if (P->fm[q].kind != kinds[q]) return false;
+  return true;
+}
+
+template <int... KINDS>
+hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpcParams *P, uint16_t *d_sizes,
+                       int8_t *d_sel, u64 *d_stats, int grid, size_t smem, hipStream_t stream)
+{
+  // OUT = per-line outputs requested (parity mode); the statistics-only build has no output code
+#define MPC_LAUNCH(WV)                                                                                              \
+  if (d_sizes || d_sel)                                                                                            \
+    hipLaunchKernelGGL((vpc_lane_kernel<WV, true, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines,     \
+                       first_line, *P, d_sizes, d_sel, d_stats);                                                   \
+  else                                                                                                             \
+    hipLaunchKernelGGL((vpc_lane_kernel<WV, false, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines,    \
+                       first_line, *P, d_sizes, d_sel, d_stats)
+  switch (P->L) {
+  case 32: MPC_LAUNCH(8); break;
+  case 64: MPC_LAUNCH(16); break;
+  default: return hipErrorInvalidValue;
+  }
+#undef MPC_LAUNCH
+  return hipGetLastError();
+}
+
+// the module sequences this kernel is instantiated for
+#define MPC_LANE_SEQUENCES(X) X(OB, CS, DF, WT) X(OB, CS) X(OB) X(CS) X(DF) X(WT)
+
+}  // namespace
+
+// 1 when the lane-per-line kernel covers the configuration (else mpc_vpc_fast.hip runs it)
+extern "C" int mpc_vpc_lane_supported(const MpcVpcParams *P)
+{
+  if (P->L != 32 && P->L != 64) return 0;
+#define X(...) if (lane_seq_matches<__VA_ARGS__>(P)) return 1;
+  MPC_LANE_SEQUENCES(X)
+#undef X
+  return 0;
+}
+
+extern "C" size_t mpc_vpc_lane_smem(const MpcVpcParams *P) { return vpc_stats_smem(P->M + 1, P->hist_bins); }
+
+extern "C" hipError_t mpc_launch_vpc_lane(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
+                                          int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
+{
+  const size_t smem = mpc_vpc_lane_smem(P);
+  const u64 max_lines = 1ull << 30;     // 32-bit line indices inside the kernel
+  for (u64 done = 0; done < n_lines; done += max_lines) {
+    const u64 take = (n_lines - done) < max_lines ? (n_lines - done) : max_lines;
+    const uint4 *l = static_cast<const uint4 *>(d_lines) + done * (u64)(P->L / 16);
+    hipError_t e = hipErrorInvalidValue;
+    bool launched = false;
+#define X(...)                                                                                                     \
+    if (!launched && lane_seq_matches<__VA_ARGS__>(P)) {                                                           \
+      e = lane_launch<__VA_ARGS__>(l, (u32)take, done, P, d_sizes, d_sel, d_stats, grid, smem, stream);            \
+      launched = true;                                                                                             \
+    }
+    MPC_LANE_SEQUENCES(X)
+#undef X
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
