@@ -17,6 +17,10 @@
 // residues, row-0 prefilter, incompressibility certificate) are the same.
 #include "mpc_kernel_common.h"
 
+#ifndef MPC_ABLATE
+#define MPC_ABLATE 0   // development-only timing ablations (tools/ablate.sh); results are WRONG when non-zero
+#endif
+
 namespace {
 
 template <int W>
@@ -136,45 +140,102 @@ struct LaneBest {
   u32 cx;
 };
 
+// ---- module sequence -------------------------------------------------------------
+// Pass 1: row-0 prefilters of all modules but the last -> wave-uniform bit mask of the
+// modules that have to be evaluated (bit Q: some needed line has a clear row 0).
 template <int W, int NPT, int Q>
-__device__ __forceinline__ void lane_seq(const Lane<W> &, const MpcVpcParams &, u64, LaneBest<W> &, bool) {}
+__device__ __forceinline__ u32 lane_prefilters(const Lane<W> &, const MpcVpcParams &, u64) { return 0; }
 
-// modules in order; a module that the wave-uniform row-0 prefilter rules out everywhere is skipped
 template <int W, int NPT, int Q, int KIND, int... REST>
-__device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P, u64 need_mask, LaneBest<W> &best,
+__device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcParams &P, u64 need_mask)
+{
+  if constexpr (Q + 1 == NPT) {
+    return 0;
+  } else {
+    u32 bit = 0;
+    if constexpr (!(MPC_ABLATE & 8)) {
+      const u32 msb = lane_row0<W, KIND>(c, P.fm[Q], P.tab);
+      bit = ((__ballot(msb != 0) & need_mask) != need_mask) ? (1u << Q) : 0u;
+    }
+    return bit | lane_prefilters<W, NPT, Q + 1, REST...>(c, P, need_mask);
+  }
+}
+
+// Pass 2 (only when pass 1 kept a module): the kept modules and the last one in order,
+// winner updated with selects.
+template <int W, int NPT, int Q>
+__device__ __forceinline__ void lane_seq(const Lane<W> &, const MpcVpcParams &, u32, LaneBest<W> &, bool) {}
+
+template <int W, int NPT, int Q, int KIND, int... REST>
+__device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P, u32 keep_bits, LaneBest<W> &best,
                                          bool any_full)
 {
-  const bool last = Q + 1 == NPT;
-  bool full = true;
-  if constexpr (!last) {
-    const u32 msb = lane_row0<W, KIND>(c, P.fm[Q], P.tab);
-    full = (__ballot(msb != 0) & need_mask) != need_mask;    // some needed line has a clear row 0
-  }
-  if (full) {
+  constexpr bool last = Q + 1 == NPT;
+  if (last || (keep_bits & (1u << Q))) {
     u32 r[W], root_r;
     lane_residue<W, KIND>(c, P.fm[Q], P.tab, r, root_r);
-    if (any_full) {
-      const u32 z = lane_leading_zero_rows<W>(r);
-      const bool take = best.z <= z;     // ties go to the later module (VPC.cpp:389)
-      best.z = take ? z : best.z;
-      best.q = take ? Q : best.q;
-      best.root_r = take ? root_r : best.root_r;
-      best.cx = take ? (u32)P.fm[Q].cx : best.cx;
+    const u32 z = lane_leading_zero_rows<W>(r);
+    const bool take = !any_full || best.z <= z;     // ties go to the later module (VPC.cpp:389)
+    best.z = take ? z : best.z;
+    best.q = take ? Q : best.q;
+    best.root_r = take ? root_r : best.root_r;
+    best.cx = take ? (u32)P.fm[Q].cx : best.cx;
 #pragma unroll
-      for (int e = 0; e < W; e++) best.r[e] = take ? r[e] : best.r[e];
-    } else {
-      // first candidate of this wave (best is not initialised before); the last module's z
-      // only matters against an earlier candidate
-      if constexpr (!last) best.z = lane_leading_zero_rows<W>(r);
-      best.q = Q;
-      best.root_r = root_r;
-      best.cx = (u32)P.fm[Q].cx;
-#pragma unroll
-      for (int e = 0; e < W; e++) best.r[e] = r[e];
-    }
+    for (int e = 0; e < W; e++) best.r[e] = take ? r[e] : best.r[e];
     any_full = true;
   }
-  if constexpr (!last) lane_seq<W, NPT, Q + 1, REST...>(c, P, need_mask, best, any_full);
+  if constexpr (!last) lane_seq<W, NPT, Q + 1, REST...>(c, P, keep_bits, best, any_full);
+}
+
+// the last module alone (pass 1 ruled out every other module for the whole wave)
+template <int W, int NPT, int Q>
+__device__ __forceinline__ void lane_last(const Lane<W> &, const MpcVpcParams &, LaneBest<W> &) {}
+
+template <int W, int NPT, int Q, int KIND, int... REST>
+__device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &P, LaneBest<W> &best)
+{
+  if constexpr (Q + 1 == NPT) {
+    lane_residue<W, KIND>(c, P.fm[Q], P.tab, best.r, best.root_r);
+    best.q = Q;
+    best.cx = (u32)P.fm[Q].cx;
+  } else {
+    lane_last<W, NPT, Q + 1, REST...>(c, P, best);
+  }
+}
+
+// byte j of the result = OR of the four bytes of X[j] (NG == 4), or bytes 0 / 2 for X[0] / X[1] (NG == 2)
+template <int NG>
+__device__ __forceinline__ u32 fold_pack(const u32 (&X)[NG])
+{
+  const u32 a01 = perm(X[1], X[0], 0x05040100u) | perm(X[1], X[0], 0x07060302u);   // [X0.b0|b2, X0.b1|b3, X1.b0|b2, X1.b1|b3]
+  if constexpr (NG == 2) {
+    return (a01 | (a01 >> 8)) & 0x00ff00ffu;
+  } else {
+    const u32 a23 = perm(X[3], X[2], 0x05040100u) | perm(X[3], X[2], 0x07060302u);
+    return perm(a23, a01, 0x06040200u) | perm(a23, a01, 0x07050301u);
+  }
+}
+
+// Incompressibility certificate, a lower bound of the common encoder's size: a row whose
+// two 8-column halves are both non-zero and that has a bit outside columns 7/8 costs 17
+// bits (it is neither a single one nor an adjacent pair, FPCModule.cpp:50-69); any other
+// non-zero row costs at least 7; a zero row sits in a run that costs at least 4.
+// True: the encoding cannot beat 8*L bits, the encoder need not run.
+template <int W>
+__device__ __forceinline__ bool lane_certified(const u32 (&t)[W])
+{
+  constexpr int NG = W / 4;
+  u32 F[NG], B[NG], O[NG];
+#pragma unroll
+  for (int j = 0; j < NG; j++) {
+    F[j] = t[4 * j] | t[4 * j + 1];
+    B[j] = t[4 * j + 2] | t[4 * j + 3];
+    O[j] = (t[4 * j] | (t[4 * j + 1] & 0x00ffffffu)) | ((t[4 * j + 2] & 0xffffff00u) | t[4 * j + 3]);
+  }
+  const u32 Sf = fold_pack<NG>(F), Sb = fold_pack<NG>(B), So = fold_pack<NG>(O);
+  const u32 n17 = (u32)__popc(Sf & Sb & So), nnz = (u32)__popc(Sf | Sb);
+  const u32 bound = 10u * n17 + 7u * nnz + (nnz != 2u * W ? 4u : 0u);
+  return bound >= 32u * W;
 }
 
 // common encoder (FPCModule.cpp:19-85) over all rows of the line: non-zero rows by
@@ -218,6 +279,138 @@ __device__ __forceinline__ void lane_run_flush(const LaneRun &rs, const WgStats 
   }
 }
 
+// per-wave constants and run state of the kernel loop
+struct LaneEnv {
+  WgStats st;
+  int K, bins;
+  u32 enc_zero, enc_same, enc_unc;
+  u32 n_lines, lane;
+  u64 first_line;
+  uint16_t *sizes_out;
+  int8_t *sel_out;
+};
+
+// one group of 64 lines: lane i evaluates line line0 + i, held in v[]
+template <int W, bool OUT, int... KINDS>
+__device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, const MpcVpcParams &P, const LaneEnv &E,
+                                          LaneRun &rs)
+{
+  constexpr int L = 4 * W;
+  constexpr int NQ = W / 4;
+  constexpr int NPT = sizeof...(KINDS);
+  constexpr u32 uncomp = 8u * L;
+  const bool valid = line0 + E.lane < E.n_lines;
+  Lane<W> c;
+#pragma unroll
+  for (int i = 0; i < NQ; i++) {
+    c.x[4 * i] = v[i].x; c.x[4 * i + 1] = v[i].y; c.x[4 * i + 2] = v[i].z; c.x[4 * i + 3] = v[i].w;
+  }
+
+  // ---- AllZero / AllWordSame (VPC.cpp:332-364) ----
+  u32 diff = 0;
+#pragma unroll
+  for (int e = 1; e < W; e++) diff |= c.x[e] ^ c.x[0];
+  const bool is_rep = diff == 0;                       // every word equals word 0
+  const bool is_zero = (diff | c.x[0]) == 0;
+  const bool need = valid && !(is_zero || (P.has_aws && is_rep));
+  const u64 need_mask = __ballot(need);
+
+  int chosen = is_zero ? 0 : 1;
+  u32 size = is_zero ? E.enc_zero : E.enc_same;
+  u32 sum_r = 0, sum_r2 = 0;        // residue statistics of this line (VPC.cpp:417-443)
+
+  if (need_mask) {     // wave-uniform: some line needs the prediction modules
+    c.b0 = c.x[0] & 0xffu;
+    c.rootb = perm(c.x[0], c.x[0], 0u);
+    LaneBest<W> best;
+    const u32 keep_bits = lane_prefilters<W, NPT, 0, KINDS...>(c, P, need_mask);
+    if (keep_bits == 0) lane_last<W, NPT, 0, KINDS...>(c, P, best);
+    else lane_seq<W, NPT, 0, KINDS...>(c, P, keep_bits, best, false);
+
+    // XOR stage of the winner, on bytes: b ^ (b >> 1), or b ^ 0x7f where the MSB is set;
+    // column 0 untouched.  The flavour is usually the same for the whole wave.
+    u32 t[W];
+    const u64 cx_mask = __ballot(best.cx != 0);
+    if ((cx_mask & need_mask) == need_mask) {
+#pragma unroll
+      for (int e = 0; e < W; e++) t[e] = best.r[e] ^ ((best.r[e] >> 1) & (e == 0 ? 0x7f7f7f00u : L7F));
+    } else {
+#pragma unroll
+      for (int e = 0; e < W; e++) {
+        const u32 m = (best.r[e] >> 7) & 0x01010101u;
+        const u32 f = best.cx ? ((best.r[e] >> 1) & L7F) : ((m << 7) - m);
+        t[e] = best.r[e] ^ (e == 0 ? (f & 0xffffff00u) : f);
+      }
+    }
+    bool open = need;
+    if constexpr (!(MPC_ABLATE & 2)) open = need && !lane_certified<W>(t);
+    else open = need && (t[0] == 12345u);
+    u32 enc = uncomp;
+    if (__ballot(open)) enc = lane_encode<W>(t);
+    const bool keep = open && enc < uncomp;             // VPC.cpp:397-407
+    const u64 keep_mask = __ballot(keep);
+
+    // residue statistics over all positions: the winner's residues (the root position
+    // holds best.root_r, not the raw root), or the raw bytes when the line stays
+    // uncompressed; nothing for AllZero / AllWordSame lines (VPC.cpp:412 is not reached)
+    if constexpr (MPC_ABLATE & 4) { sum_r = c.x[3]; sum_r2 = c.x[5]; } else
+    if (keep_mask == 0) {
+#pragma unroll
+      for (int e = 0; e < W; e++) {
+        sum_r = sum_bytes(c.x[e], sum_r);
+        sum_r2 = sum_sq_bytes(c.x[e], sum_r2);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < W; e++) {
+        u32 w = keep ? best.r[e] : c.x[e];
+        if (e == 0) w = keep ? ((w & 0xffffff00u) | best.root_r) : w;
+        sum_r = sum_bytes(w, sum_r);
+        sum_r2 = sum_sq_bytes(w, sum_r2);
+      }
+    }
+    sum_r = need ? sum_r : 0u;
+    sum_r2 = need ? sum_r2 : 0u;
+    if (need) {
+      chosen = keep ? P.start + best.q : -1;
+      size = keep ? enc + (u32)P.enc_bits[chosen + 1] : uncomp + E.enc_unc;
+    }
+  }
+
+  // ---- statistics: run-length per lane ----
+  const u32 key = ((u32)(chosen + 1) << 16) | size;
+  if (valid) {
+    if (key != rs.key) {
+      lane_run_flush(rs, E.st, E.K, E.bins);
+      rs.key = key;
+      rs.cnt = 0;
+      rs.acc_r = 0;
+      rs.acc_r2 = 0;
+    }
+    rs.cnt++;
+    rs.acc_r += sum_r;
+    rs.acc_r2 += sum_r2;
+  }
+
+  // ---- per-line outputs (parity mode) ----
+  if constexpr (OUT) {
+    if (valid) {
+      const u64 line = E.first_line + line0 + E.lane;
+      if (E.sizes_out) E.sizes_out[line] = (uint16_t)size;
+      if (E.sel_out) E.sel_out[line] = (int8_t)chosen;
+    }
+  }
+}
+
+template <int NQ>
+__device__ __forceinline__ void lane_fetch(uint4 (&v)[NQ], const uint4 *__restrict__ lines, u32 line, u32 n_lines)
+{
+  // clamped: past the end it re-reads the last line (never evaluated: `valid` is false there)
+  const uint4 *src = lines + (u64)min(line, n_lines - 1u) * NQ;
+#pragma unroll
+  for (int i = 0; i < NQ; i++) v[i] = src[i];
+}
+
 // n_lines < 2^31 per launch (the host splits larger batches)
 template <int W, bool OUT, int... KINDS>
 __global__ void __launch_bounds__(256)
@@ -225,19 +418,21 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
                 uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int L = 4 * W;
   constexpr int NQ = W / 4;             // 16-byte pieces per line
-  constexpr int NPT = sizeof...(KINDS);
-  const int K = P.M + 1, bins = P.hist_bins;
-  WgStats st;
-  st.sums = reinterpret_cast<u64 *>(smem);
-  st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * K * 8 + 15) / 16));
-  stats_init(st, K, bins);   // ends with __syncthreads()
-
-  const u32 lane = threadIdx.x & 63;
-  const u32 uncomp = 8u * L;
-  const u32 enc_zero = (u32)P.enc_bits[1], enc_same = 32u + (u32)P.enc_bits[2], enc_unc = (u32)P.enc_bits[0];
-  const u32 cert_min = (u32)P.cert_min17;
+  LaneEnv E;
+  E.K = P.M + 1;
+  E.bins = P.hist_bins;
+  E.st.sums = reinterpret_cast<u64 *>(smem);
+  E.st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * E.K * 8 + 15) / 16));
+  stats_init(E.st, E.K, E.bins);   // ends with __syncthreads()
+  E.enc_zero = (u32)P.enc_bits[1];
+  E.enc_same = 32u + (u32)P.enc_bits[2];
+  E.enc_unc = (u32)P.enc_bits[0];
+  E.n_lines = n_lines;
+  E.lane = threadIdx.x & 63;
+  E.first_line = first_line;
+  E.sizes_out = sizes_out;
+  E.sel_out = sel_out;
 
   LaneRun rs = {0xffffffffu, 0, 0, 0};
   u32 iter = 0;
@@ -246,138 +441,27 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 stride = gridDim.x * 256u;
   u32 line0 = (blockIdx.x * 4u + wave) * 64u;
-  uint4 vnext[NQ];
-  if (line0 < n_lines) {
-    const uint4 *src = lines + (u64)min(line0 + lane, n_lines - 1u) * NQ;
-#pragma unroll
-    for (int i = 0; i < NQ; i++) vnext[i] = src[i];
-  }
 
-  for (; line0 < n_lines; line0 += stride) {
-    const bool valid = line0 + lane < n_lines;
-    Lane<W> c;
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-      c.x[4 * i] = vnext[i].x; c.x[4 * i + 1] = vnext[i].y; c.x[4 * i + 2] = vnext[i].z; c.x[4 * i + 3] = vnext[i].w;
-    }
-    {
-      // prefetch the next iteration (clamped: past the end it re-reads the last line)
-      const uint4 *src = lines + (u64)min(line0 + stride + lane, n_lines - 1u) * NQ;
-#pragma unroll
-      for (int i = 0; i < NQ; i++) vnext[i] = src[i];
-    }
-
-    // ---- AllZero / AllWordSame (VPC.cpp:332-364) ----
-    u32 diff = 0;
-#pragma unroll
-    for (int e = 1; e < W; e++) diff |= c.x[e] ^ c.x[0];
-    const bool is_rep = diff == 0;                       // every word equals word 0
-    const bool is_zero = (diff | c.x[0]) == 0;
-    const bool need = valid && !(is_zero || (P.has_aws && is_rep));
-    const u64 need_mask = __ballot(need);
-
-    int chosen = is_zero ? 0 : 1;
-    u32 size = is_zero ? enc_zero : enc_same;
-    u32 sum_r = 0, sum_r2 = 0;        // residue statistics of this line (VPC.cpp:417-443)
-
-    if (need_mask) {     // wave-uniform: some line needs the prediction modules
-      c.b0 = c.x[0] & 0xffu;
-      c.rootb = perm(c.x[0], c.x[0], 0u);
-      LaneBest<W> best;
-      lane_seq<W, NPT, 0, KINDS...>(c, P, need_mask, best, false);
-
-      // XOR stage of the winner, on bytes: b ^ (b >> 1), or b ^ 0x7f where the MSB is set;
-      // column 0 untouched.  The flavour is usually the same for the whole wave.
-      u32 t[W];
-      const u64 cx_mask = __ballot(best.cx != 0);
-      if ((cx_mask & need_mask) == need_mask) {
-#pragma unroll
-        for (int e = 0; e < W; e++) {
-          const u32 f = (best.r[e] >> 1) & (e == 0 ? 0x7f7f7f00u : L7F);
-          t[e] = best.r[e] ^ f;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < W; e++) {
-          const u32 m = (best.r[e] >> 7) & 0x01010101u;
-          const u32 f = best.cx ? ((best.r[e] >> 1) & L7F) : ((m << 7) - m);
-          t[e] = best.r[e] ^ (e == 0 ? (f & 0xffffff00u) : f);
-        }
-      }
-      // Incompressibility certificate: a row whose two 8-column halves are both non-zero
-      // and that has a bit outside columns 7/8 costs 17 bits (it is neither a single one
-      // nor an adjacent pair).  With cert_min17 such rows the line cannot beat 8*L bits.
-      u32 n17 = 0;
-#pragma unroll
-      for (int j = 0; j < NQ; j++) {
-        const u32 Sf = fold8(t[4 * j] | t[4 * j + 1]), Sb = fold8(t[4 * j + 2] | t[4 * j + 3]);
-        const u32 So = fold8(t[4 * j] | (t[4 * j + 1] & 0x00ffffffu) | (t[4 * j + 2] & 0xffffff00u) | t[4 * j + 3]);
-        n17 += (u32)__popc(Sf & Sb & So);
-      }
-      const bool open = need && n17 < cert_min;
-      u32 enc = uncomp;
-      if (__ballot(open)) enc = lane_encode<W>(t);
-      const bool keep = open && enc < uncomp;             // VPC.cpp:397-407
-      const u64 keep_mask = __ballot(keep);
-
-      // residue statistics over all positions: the winner's residues (the root position
-      // holds best.root_r, not the raw root), or the raw bytes when the line stays
-      // uncompressed; nothing for AllZero / AllWordSame lines (VPC.cpp:412 is not reached)
-      if (keep_mask == 0) {
-#pragma unroll
-        for (int e = 0; e < W; e++) {
-          sum_r = sum_bytes(c.x[e], sum_r);
-          sum_r2 = sum_sq_bytes(c.x[e], sum_r2);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < W; e++) {
-          u32 v = keep ? best.r[e] : c.x[e];
-          if (e == 0) v = keep ? ((v & 0xffffff00u) | best.root_r) : v;
-          sum_r = sum_bytes(v, sum_r);
-          sum_r2 = sum_sq_bytes(v, sum_r2);
-        }
-      }
-      sum_r = need ? sum_r : 0u;
-      sum_r2 = need ? sum_r2 : 0u;
-      if (need) {
-        chosen = keep ? P.start + best.q : -1;
-        size = keep ? enc + (u32)P.enc_bits[chosen + 1] : uncomp + enc_unc;
-      }
-    }
-
-    // ---- statistics: run-length per lane ----
-    const u32 key = ((u32)(chosen + 1) << 16) | size;
-    if (valid) {
-      if (key != rs.key) {
-        lane_run_flush(rs, st, K, bins);
-        rs.key = key;
-        rs.cnt = 0;
-        rs.acc_r = 0;
-        rs.acc_r2 = 0;
-      }
-      rs.cnt++;
-      rs.acc_r += sum_r;
-      rs.acc_r2 += sum_r2;
-    }
-    if ((++iter & 255u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
-      lane_run_flush(rs, st, K, bins);
+  // two line buffers: the next group of 64 lines is in flight while this one is evaluated
+  uint4 va[NQ], vb[NQ];
+  if (line0 < n_lines) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
+  while (line0 < n_lines) {
+    lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
+    lane_step<W, OUT, KINDS...>(va, line0, P, E, rs);
+    line0 += stride;
+    if (line0 >= n_lines) break;
+    lane_fetch<NQ>(va, lines, line0 + stride + E.lane, n_lines);
+    lane_step<W, OUT, KINDS...>(vb, line0, P, E, rs);
+    line0 += stride;
+    if ((++iter & 127u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
+      lane_run_flush(rs, E.st, E.K, E.bins);
       rs.cnt = 0;
       rs.acc_r = 0;
       rs.acc_r2 = 0;
     }
-
-    // ---- per-line outputs (parity mode) ----
-    if constexpr (OUT) {
-      if (valid) {
-        const u64 line = first_line + line0 + lane;
-        if (sizes_out) sizes_out[line] = (uint16_t)size;
-        if (sel_out) sel_out[line] = (int8_t)chosen;
-      }
-    }
   }
-  lane_run_flush(rs, st, K, bins);
-  stats_flush(st, K, bins, gstats);
+  lane_run_flush(rs, E.st, E.K, E.bins);
+  stats_flush(E.st, E.K, E.bins, gstats);
 }
 
 #define OB MPC_FK_ONEBASE
@@ -437,7 +521,19 @@ extern "C" size_t mpc_vpc_lane_smem(const MpcVpcParams *P) { return vpc_stats_sm
 extern "C" hipError_t mpc_launch_vpc_lane(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
                                           int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
 {
-  const size_t smem = mpc_vpc_lane_smem(P);
+  size_t smem = mpc_vpc_lane_smem(P);
+#ifdef MPC_DEV_LDS_PAD
+  if (const char *e = getenv("MPC_DEV_LDS_PAD")) {   // development: limit the waves per SIMD through the LDS footprint
+    smem += (size_t)atoi(e);
+    static bool once = false;
+    if (!once) {
+      once = true;
+#define X(...) hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_lane_kernel<16, false, __VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      MPC_LANE_SEQUENCES(X)
+#undef X
+    }
+  }
+#endif
   const u64 max_lines = 1ull << 30;     // 32-bit line indices inside the kernel
   for (u64 done = 0; done < n_lines; done += max_lines) {
     const u64 take = (n_lines - done) < max_lines ? (n_lines - done) : max_lines;
