@@ -433,7 +433,7 @@ int mpc_get_info(const mpc_handle *h, mpc_info *info)
   info->num_modules = h->algorithm == 0 ? h->cfg.M : 0;
   info->num_clusters = h->algorithm == 0 ? h->cfg.M + 1 : 9;
   info->hist_bins = h->algorithm == 0 ? h->cfg.hist_bins : 0;
-  info->kernel_path = h->algorithm == 1 ? MPC_PATH_BDI : (h->plan.fast ? MPC_PATH_VPC_FAST : MPC_PATH_VPC_GENERIC);
+  info->kernel_path = h->algorithm == 1 ? MPC_PATH_BDI : (h->plan.fast ? (h->lane_kernel ? MPC_PATH_VPC_LANE : MPC_PATH_VPC_FAST) : MPC_PATH_VPC_GENERIC);
   info->device = h->device;
   info->stats_len = h->stats_len;
   return MPC_OK;

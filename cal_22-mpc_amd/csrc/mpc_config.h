@@ -331,6 +331,12 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     plan.tab.insert(plan.tab.end(), sel.begin(), sel.end());
     plan.tab.insert(plan.tab.end(), c1.begin(), c1.end());
     plan.tab.insert(plan.tab.end(), c2.begin(), c2.end());
+    // c1 split into its low-7-bit and MSB parts (lane-per-line kernel, WeightBase residue)
+    for (size_t w = 0; w < c1.size(); w++) plan.tab.push_back(c1[w] & 0x7f7f7f7fu);
+    for (size_t w = 0; w < c1.size(); w++) plan.tab.push_back(c1[w] & 0x80808080u);
+    f.prev_word = 1;
+    for (size_t w = 1; w < sel.size(); w++)
+      if (sel[w] != 0x03020100u) f.prev_word = 0;
   }
   while (plan.tab.size() % 4) plan.tab.push_back(0);
   if (plan.tab.empty()) plan.tab.assign(4, 0);

@@ -23,6 +23,11 @@
 
 namespace {
 
+// lane-kernel predictor kinds: MPC_FK_* plus LK_PW when every base byte of words 1.. is the
+// same byte of the previous word (MpcFastModule::prev_word): no v_perm_b32 needed
+constexpr int LK_PW = 8;
+__device__ __host__ constexpr int lk_base(int kind) { return kind & 7; }
+
 template <int W>
 struct Lane {
   u32 x[W];    // the line
@@ -51,6 +56,45 @@ __device__ __forceinline__ u32 shuffled_word(const u32 (&x)[W], int j)
   return plane_bytes<W>(x, j % NG, 3 - j / NG);
 }
 
+// predicted word from the base bytes b (see window_predict in mpc_kernel_common.h)
+template <int KIND>
+__device__ __forceinline__ u32 window_predict(u32 b, u32 c1, u32 c2, const MpcFastModule &fm)
+{
+  if constexpr (KIND == MPC_FK_DIFF)
+    return ((b & L7F) + c1) ^ ((b & H80) ^ c2);   // per-byte b + diff; the host split diff into c1 = low 7 bits, c2 = MSBs
+  else if constexpr (KIND == MPC_FK_WEIGHT)
+    return (b & c1) | ((b >> fm.rs2) & c2);
+  else
+    return (((b << fm.ls1) >> fm.rs1) & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
+}
+
+// base bytes of word e: own / previous word through v_perm_b32, or simply the previous word
+template <int W, int KIND>
+__device__ __forceinline__ u32 window_base(const Lane<W> &c, int e, const u32 *__restrict__ t)
+{
+  if ((KIND & LK_PW) && e > 0) return c.x[e - 1];
+  return perm(c.x[e], e ? c.x[e - 1] : 0u, t[e]);
+}
+
+// residue word e of a DiffBase / WeightBase module.  full = false: only bit 7 of each
+// byte is meaningful (the MSBs the row-0 prefilter looks at)
+template <int W, int KIND, bool FULL = true>
+__device__ __forceinline__ u32 window_residue(const Lane<W> &c, int e, const u32 *__restrict__ t, const MpcFastModule &fm)
+{
+  const u32 b = window_base<W, KIND>(c, e, t);
+  if constexpr (lk_base(KIND) == MPC_FK_WEIGHT) {
+    // class 1 unshifted (mask c1), class 2 shifted right (mask c2, MSBs clear): the low 7 bits
+    // and the MSB of the predicted byte come from the pre-split masks t[3W..], t[4W..]
+    const u32 p7 = ((b >> fm.rs2) & t[2 * W + e]) | (b & t[3 * W + e]);
+    const u32 sub = (c.x[e] | H80) - p7;
+    const u32 w = c.x[e] ^ (b & t[4 * W + e]);          // bit 7: line ^ predicted
+    return FULL ? (sub ^ (~w & H80)) : (sub ^ ~w);
+  } else {
+    const u32 pred = window_predict<lk_base(KIND)>(b, t[W + e], t[2 * W + e], fm);
+    return FULL ? bsub(c.x[e], pred) : msb_of_bsub(c.x[e], pred);
+  }
+}
+
 // Residue bytes (root first == natural order for RootIndex 0) of one module;
 // root_r = the residue GetMAE / GetMSE see at the root position.
 template <int W, int KIND>
@@ -58,12 +102,12 @@ __device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModu
                                              u32 (&r)[W], u32 &root_r)
 {
   root_r = 0;
-  if constexpr (KIND == MPC_FK_ONEBASE) {
+  if constexpr (lk_base(KIND) == MPC_FK_ONEBASE) {
     // predicted = line[0] everywhere; position 0 of the residue array is the raw root
     r[0] = bsub(c.x[0], c.rootb & 0xffffff00u);
 #pragma unroll
     for (int e = 1; e < W; e++) r[e] = bsub(c.x[e], c.rootb);
-  } else if constexpr (KIND == MPC_FK_CONSEC) {
+  } else if constexpr (lk_base(KIND) == MPC_FK_CONSEC) {
     // predicted[i] = inp[i - 1]; predicted byte 0 := 0 keeps the raw root at position 0
     u32 in[W];
 #pragma unroll
@@ -77,35 +121,31 @@ __device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModu
     // windowed tables; they force the predicted root byte to 0, so residue[0] = raw root
     const u32 *t = tab + fm.tab_off;
 #pragma unroll
-    for (int e = 0; e < W; e++)
-      r[e] = bsub(c.x[e], window_predict<KIND>(c.x[e], e ? c.x[e - 1] : 0u, t[e], t[W + e], t[2 * W + e], fm));
+    for (int e = 0; e < W; e++) r[e] = window_residue<W, KIND>(c, e, t, fm);
   }
 }
 
 // Row-0 prefilter: a module other than the last one can only win the selector with at
 // least one leading zero row (ties go to the later module, VPC.cpp:389), i.e. only if
-// the MSBs of residue bytes 0..15 are all clear.  Returns those MSBs ORed together.
-template <int W, int KIND>
+// the MSBs of residue bytes 0..15 are all clear.  Returns the MSBs of residue words
+// E0..E1-1 ORed together (bit 7 of each byte).
+template <int W, int KIND, int E0, int E1>
 __device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &fm, const u32 *__restrict__ tab)
 {
-  u32 m;
-  if constexpr (KIND == MPC_FK_ONEBASE) {
-    m = msb_of_bsub(c.x[0], c.rootb & 0xffffff00u);
+  u32 m = 0;
+  if constexpr (lk_base(KIND) == MPC_FK_ONEBASE) {
 #pragma unroll
-    for (int e = 1; e < 4; e++) m |= msb_of_bsub(c.x[e], c.rootb);
-  } else if constexpr (KIND == MPC_FK_CONSEC) {
-    u32 in[4];
+    for (int e = E0; e < E1; e++) m |= msb_of_bsub(c.x[e], e ? c.rootb : (c.rootb & 0xffffff00u));
+  } else if constexpr (lk_base(KIND) == MPC_FK_CONSEC) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) in[j] = shuffled_word<W>(c.x, j);
-    m = msb_of_bsub(c.x[0], in[0] << 8);
-#pragma unroll
-    for (int e = 1; e < 4; e++) m |= msb_of_bsub(c.x[e], alignbyte(in[e], in[e - 1], 3));
+    for (int e = E0; e < E1; e++) {
+      const u32 in_e = shuffled_word<W>(c.x, e);
+      m |= msb_of_bsub(c.x[e], e ? alignbyte(in_e, shuffled_word<W>(c.x, e - 1), 3) : (in_e << 8));
+    }
   } else {
     const u32 *t = tab + fm.tab_off;
-    m = 0;
 #pragma unroll
-    for (int e = 0; e < 4; e++)
-      m |= msb_of_bsub(c.x[e], window_predict<KIND>(c.x[e], e ? c.x[e - 1] : 0u, t[e], t[W + e], t[2 * W + e], fm));
+    for (int e = E0; e < E1; e++) m |= window_residue<W, KIND, false>(c, e, t, fm);
   }
   return m & H80;
 }
@@ -154,8 +194,12 @@ __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcPar
   } else {
     u32 bit = 0;
     if constexpr (!(MPC_ABLATE & 8)) {
-      const u32 msb = lane_row0<W, KIND>(c, P.fm[Q], P.tab);
-      bit = ((__ballot(msb != 0) & need_mask) != need_mask) ? (1u << Q) : 0u;
+      // words 0..2 first: on incompressible data 12 bytes almost always show an MSB
+      u32 msb = lane_row0<W, KIND, 0, 3>(c, P.fm[Q], P.tab);
+      if ((__ballot(msb != 0) & need_mask) != need_mask) {
+        msb |= lane_row0<W, KIND, 3, 4>(c, P.fm[Q], P.tab);
+        bit = ((__ballot(msb != 0) & need_mask) != need_mask) ? (1u << Q) : 0u;
+      }
     }
     return bit | lane_prefilters<W, NPT, Q + 1, REST...>(c, P, need_mask);
   }
@@ -225,14 +269,25 @@ template <int W>
 __device__ __forceinline__ bool lane_certified(const u32 (&t)[W])
 {
   constexpr int NG = W / 4;
-  u32 F[NG], B[NG], O[NG];
+  // columns 0..6 and 9..15 of every group folded to plane masks; columns 7 and 8 are whole
+  // bytes (byte 3 of word 1, byte 0 of word 2) and only need gathering
+  u32 F[NG], B[NG];
 #pragma unroll
   for (int j = 0; j < NG; j++) {
-    F[j] = t[4 * j] | t[4 * j + 1];
-    B[j] = t[4 * j + 2] | t[4 * j + 3];
-    O[j] = (t[4 * j] | (t[4 * j + 1] & 0x00ffffffu)) | ((t[4 * j + 2] & 0xffffff00u) | t[4 * j + 3]);
+    F[j] = t[4 * j] | (t[4 * j + 1] & 0x00ffffffu);
+    B[j] = (t[4 * j + 2] & 0xffffff00u) | t[4 * j + 3];
   }
-  const u32 Sf = fold_pack<NG>(F), Sb = fold_pack<NG>(B), So = fold_pack<NG>(O);
+  const u32 Sf7 = fold_pack<NG>(F), Sb7 = fold_pack<NG>(B);
+  u32 C7, C8;
+  if constexpr (NG == 2) {
+    C7 = perm(t[5], t[1], 0x0c070c03u);
+    C8 = perm(t[6], t[2], 0x0c040c00u);
+  } else {
+    C7 = perm(perm(t[13], t[9], 0x0c0c0703u), perm(t[5], t[1], 0x0c0c0703u), 0x05040100u);
+    C8 = perm(perm(t[14], t[10], 0x0c0c0400u), perm(t[6], t[2], 0x0c0c0400u), 0x05040100u);
+  }
+  const u32 Sf = Sf7 | C7, Sb = Sb7 | C8;     // front / back half non-zero
+  const u32 So = Sf7 | Sb7;                   // a bit outside columns 7 / 8
   const u32 n17 = (u32)__popc(Sf & Sb & So), nnz = (u32)__popc(Sf | Sb);
   const u32 bound = 10u * n17 + 7u * nnz + (nnz != 2u * W ? 4u : 0u);
   return bound >= 32u * W;
@@ -307,11 +362,14 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
   }
 
   // ---- AllZero / AllWordSame (VPC.cpp:332-364) ----
-  u32 diff = 0;
+  bool is_rep = false, is_zero = false;
+  if (__ballot(valid && c.x[1] == c.x[0])) {   // wave-uniform: otherwise no line of the wave can be either
+    u32 diff = 0;
 #pragma unroll
-  for (int e = 1; e < W; e++) diff |= c.x[e] ^ c.x[0];
-  const bool is_rep = diff == 0;                       // every word equals word 0
-  const bool is_zero = (diff | c.x[0]) == 0;
+    for (int e = 1; e < W; e++) diff |= c.x[e] ^ c.x[0];
+    is_rep = diff == 0;                       // every word equals word 0
+    is_zero = (diff | c.x[0]) == 0;
+  }
   const bool need = valid && !(is_zero || (P.has_aws && is_rep));
   const u64 need_mask = __ballot(need);
 
@@ -475,8 +533,11 @@ bool lane_seq_matches(const MpcVpcParams *P)
   constexpr int n = sizeof...(KINDS);
   const int kinds[n] = {KINDS...};
   if (P->n_pred != n) return false;
-  for (int q = 0; q < n; q++)
-    if (P->fm[q].kind != kinds[q]) return false;
+  for (int q = 0; q < n; q++) {
+    const MpcFastModule &f = P->fm[q];
+    const bool window = f.kind == MPC_FK_DIFF || f.kind == MPC_FK_WEIGHT || f.kind == MPC_FK_WEIGHT2;
+    if ((f.kind | ((window && f.prev_word) ? LK_PW : 0)) != kinds[q]) return false;
+  }
   return true;
 }
 
@@ -502,7 +563,9 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
 }
 
 // the module sequences this kernel is instantiated for
-#define MPC_LANE_SEQUENCES(X) X(OB, CS, DF, WT) X(OB, CS) X(OB) X(CS) X(DF) X(WT)
+#define DFP (MPC_FK_DIFF | LK_PW)
+#define WTP (MPC_FK_WEIGHT | LK_PW)
+#define MPC_LANE_SEQUENCES(X) X(OB, CS, DFP, WTP) X(OB, CS, DF, WT) X(OB, CS) X(OB) X(CS) X(DF) X(WT) X(DFP) X(WTP)
 
 }  // namespace
 
