@@ -307,7 +307,7 @@ __device__ __forceinline__ u32 lane_encode(const u32 (&t)[W])
     ZP |= Z << (8 * j);
   }
   // previous row of (p, j): (p, j-1), or (p-1, NG-1) for j = 0; next row: (p, j+1), or (p+1, 0)
-  constexpr u32 all = NG == 4 ? 0xffffffffu : ((1u << (8 * NG)) - 1u);
+  constexpr u32 all = NG == 4 ? 0xffffffffu : ((1u << (8 * (NG & 3))) - 1u);
   const u32 prevP = ((ZP << 8) & all) | (ZP >> (8 * (NG - 1) + 1));
   const u32 nextP = (ZP >> 8) | ((ZP & 0x7fu) << (8 * (NG - 1) + 1));
   const u32 starts = ZP & ~prevP;
@@ -345,8 +345,40 @@ struct LaneEnv {
   int8_t *sel_out;
 };
 
-// one group of 64 lines: lane i evaluates line line0 + i, held in v[]
-template <int W, bool OUT, int... KINDS>
+// sum and sum of squares of the bytes of W words (two chains each: the reductions are
+// latency-bound on one accumulator)
+template <int W>
+__device__ __forceinline__ void byte_sums(const u32 (&w)[W], u32 &sum, u32 &sum2)
+{
+  u32 a0 = 0, a1 = 0, q0 = 0, q1 = 0;
+#pragma unroll
+  for (int e = 0; e < W; e += 2) {
+    a0 = sum_bytes(w[e], a0);
+    q0 = sum_sq_bytes(w[e], q0);
+    a1 = sum_bytes(w[e + 1], a1);
+    q1 = sum_sq_bytes(w[e + 1], q1);
+  }
+  sum = a0 + a1;
+  sum2 = q0 + q1;
+}
+
+__device__ __forceinline__ void lane_run_add(LaneRun &rs, u32 key, u32 sum_r, u32 sum_r2, const LaneEnv &E)
+{
+  if (key != rs.key) {
+    lane_run_flush(rs, E.st, E.K, E.bins);
+    rs.key = key;
+    rs.cnt = 0;
+    rs.acc_r = 0;
+    rs.acc_r2 = 0;
+  }
+  rs.cnt++;
+  rs.acc_r += sum_r;
+  rs.acc_r2 += sum_r2;
+}
+
+// one group of 64 lines: lane i evaluates line line0 + i, held in v[].  FULL: all 64 lines
+// exist (every group but the last one of a launch), which keeps EXEC untouched on the way.
+template <int W, bool OUT, bool FULL, int... KINDS>
 __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, const MpcVpcParams &P, const LaneEnv &E,
                                           LaneRun &rs)
 {
@@ -354,7 +386,8 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
   constexpr int NQ = W / 4;
   constexpr int NPT = sizeof...(KINDS);
   constexpr u32 uncomp = 8u * L;
-  const bool valid = line0 + E.lane < E.n_lines;
+  const bool valid = FULL ? true : (line0 + E.lane < E.n_lines);
+  const u64 valid_mask = FULL ? ~0ull : __ballot(valid);
   Lane<W> c;
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
@@ -411,22 +444,27 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
     // residue statistics over all positions: the winner's residues (the root position
     // holds best.root_r, not the raw root), or the raw bytes when the line stays
     // uncompressed; nothing for AllZero / AllWordSame lines (VPC.cpp:412 is not reached)
-    if constexpr (MPC_ABLATE & 4) { sum_r = c.x[3]; sum_r2 = c.x[5]; } else
-    if (keep_mask == 0) {
-#pragma unroll
-      for (int e = 0; e < W; e++) {
-        sum_r = sum_bytes(c.x[e], sum_r);
-        sum_r2 = sum_sq_bytes(c.x[e], sum_r2);
+    if (keep_mask == 0 && need_mask == valid_mask) {
+      // every line of the group stays uncompressed (the common case on incompressible data):
+      // one wave-uniform key, sums of the raw bytes
+      if constexpr (MPC_ABLATE & 4) { sum_r = c.x[3]; sum_r2 = c.x[5]; }
+      else byte_sums<W>(c.x, sum_r, sum_r2);
+      const u32 unc_size = uncomp + E.enc_unc;
+      if (valid) lane_run_add(rs, unc_size, sum_r, sum_r2, E);       // cluster -1: key = size
+      if constexpr (OUT) {
+        if (valid) {
+          const u64 line = E.first_line + line0 + E.lane;
+          if (E.sizes_out) E.sizes_out[line] = (uint16_t)unc_size;
+          if (E.sel_out) E.sel_out[line] = (int8_t)-1;
+        }
       }
-    } else {
-#pragma unroll
-      for (int e = 0; e < W; e++) {
-        u32 w = keep ? best.r[e] : c.x[e];
-        if (e == 0) w = keep ? ((w & 0xffffff00u) | best.root_r) : w;
-        sum_r = sum_bytes(w, sum_r);
-        sum_r2 = sum_sq_bytes(w, sum_r2);
-      }
+      return;
     }
+    u32 w[W];
+#pragma unroll
+    for (int e = 0; e < W; e++) w[e] = keep ? best.r[e] : c.x[e];
+    w[0] = keep ? ((w[0] & 0xffffff00u) | best.root_r) : w[0];
+    byte_sums<W>(w, sum_r, sum_r2);
     sum_r = need ? sum_r : 0u;
     sum_r2 = need ? sum_r2 : 0u;
     if (need) {
@@ -436,19 +474,7 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
   }
 
   // ---- statistics: run-length per lane ----
-  const u32 key = ((u32)(chosen + 1) << 16) | size;
-  if (valid) {
-    if (key != rs.key) {
-      lane_run_flush(rs, E.st, E.K, E.bins);
-      rs.key = key;
-      rs.cnt = 0;
-      rs.acc_r = 0;
-      rs.acc_r2 = 0;
-    }
-    rs.cnt++;
-    rs.acc_r += sum_r;
-    rs.acc_r2 += sum_r2;
-  }
+  if (valid) lane_run_add(rs, ((u32)(chosen + 1) << 16) | size, sum_r, sum_r2, E);
 
   // ---- per-line outputs (parity mode) ----
   if constexpr (OUT) {
@@ -466,7 +492,15 @@ __device__ __forceinline__ void lane_fetch(uint4 (&v)[NQ], const uint4 *__restri
   // clamped: past the end it re-reads the last line (never evaluated: `valid` is false there)
   const uint4 *src = lines + (u64)min(line, n_lines - 1u) * NQ;
 #pragma unroll
-  for (int i = 0; i < NQ; i++) v[i] = src[i];
+  for (int i = 0; i < NQ; i++) {
+#ifdef MPC_DEV_NT
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(src + i));
+    v[i] = make_uint4(q.x, q.y, q.z, q.w);
+#else
+    v[i] = src[i];
+#endif
+  }
 }
 
 // n_lines < 2^31 per launch (the host splits larger batches)
@@ -505,11 +539,13 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
   if (line0 < n_lines) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
   while (line0 < n_lines) {
     lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
-    lane_step<W, OUT, KINDS...>(va, line0, P, E, rs);
+    if (line0 + 64u <= n_lines) lane_step<W, OUT, true, KINDS...>(va, line0, P, E, rs);
+    else lane_step<W, OUT, false, KINDS...>(va, line0, P, E, rs);
     line0 += stride;
     if (line0 >= n_lines) break;
     lane_fetch<NQ>(va, lines, line0 + stride + E.lane, n_lines);
-    lane_step<W, OUT, KINDS...>(vb, line0, P, E, rs);
+    if (line0 + 64u <= n_lines) lane_step<W, OUT, true, KINDS...>(vb, line0, P, E, rs);
+    else lane_step<W, OUT, false, KINDS...>(vb, line0, P, E, rs);
     line0 += stride;
     if ((++iter & 127u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
       lane_run_flush(rs, E.st, E.K, E.bins);
