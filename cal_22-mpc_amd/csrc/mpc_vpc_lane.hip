@@ -269,26 +269,33 @@ template <int W>
 __device__ __forceinline__ bool lane_certified(const u32 (&t)[W])
 {
   constexpr int NG = W / 4;
-  // columns 0..6 and 9..15 of every group folded to plane masks; columns 7 and 8 are whole
-  // bytes (byte 3 of word 1, byte 0 of word 2) and only need gathering
-  u32 F[NG], B[NG];
+  constexpr int GP = NG < 4 ? NG : 4;      // column groups per packed word
+  u32 n17 = 0, nnz = 0;
 #pragma unroll
-  for (int j = 0; j < NG; j++) {
-    F[j] = t[4 * j] | (t[4 * j + 1] & 0x00ffffffu);
-    B[j] = (t[4 * j + 2] & 0xffffff00u) | t[4 * j + 3];
+  for (int h = 0; h < NG / GP; h++) {
+    const u32 *th = &t[16 * h];
+    // columns 0..6 and 9..15 of every group folded to plane masks; columns 7 and 8 are whole
+    // bytes (byte 3 of word 1, byte 0 of word 2) and only need gathering
+    u32 F[GP], B[GP];
+#pragma unroll
+    for (int j = 0; j < GP; j++) {
+      F[j] = th[4 * j] | (th[4 * j + 1] & 0x00ffffffu);
+      B[j] = (th[4 * j + 2] & 0xffffff00u) | th[4 * j + 3];
+    }
+    const u32 Sf7 = fold_pack<GP>(F), Sb7 = fold_pack<GP>(B);
+    u32 C7, C8;
+    if constexpr (GP == 2) {
+      C7 = perm(th[5], th[1], 0x0c070c03u);
+      C8 = perm(th[6], th[2], 0x0c040c00u);
+    } else {
+      C7 = perm(perm(th[13], th[9], 0x0c0c0703u), perm(th[5], th[1], 0x0c0c0703u), 0x05040100u);
+      C8 = perm(perm(th[14], th[10], 0x0c0c0400u), perm(th[6], th[2], 0x0c0c0400u), 0x05040100u);
+    }
+    const u32 Sf = Sf7 | C7, Sb = Sb7 | C8;     // front / back half non-zero
+    const u32 So = Sf7 | Sb7;                   // a bit outside columns 7 / 8
+    n17 += (u32)__popc(Sf & Sb & So);
+    nnz += (u32)__popc(Sf | Sb);
   }
-  const u32 Sf7 = fold_pack<NG>(F), Sb7 = fold_pack<NG>(B);
-  u32 C7, C8;
-  if constexpr (NG == 2) {
-    C7 = perm(t[5], t[1], 0x0c070c03u);
-    C8 = perm(t[6], t[2], 0x0c040c00u);
-  } else {
-    C7 = perm(perm(t[13], t[9], 0x0c0c0703u), perm(t[5], t[1], 0x0c0c0703u), 0x05040100u);
-    C8 = perm(perm(t[14], t[10], 0x0c0c0400u), perm(t[6], t[2], 0x0c0c0400u), 0x05040100u);
-  }
-  const u32 Sf = Sf7 | C7, Sb = Sb7 | C8;     // front / back half non-zero
-  const u32 So = Sf7 | Sb7;                   // a bit outside columns 7 / 8
-  const u32 n17 = (u32)__popc(Sf & Sb & So), nnz = (u32)__popc(Sf | Sb);
   const u32 bound = 10u * n17 + 7u * nnz + (nnz != 2u * W ? 4u : 0u);
   return bound >= 32u * W;
 }
@@ -299,19 +306,20 @@ template <int W>
 __device__ __forceinline__ u32 lane_encode(const u32 (&t)[W])
 {
   constexpr int NG = W / 4;
-  u32 bits = 0, ZP = 0;     // byte j of ZP: zero-row mask of column group j (bit 7-p = plane p)
+  u32 bits = 0;
+  u64 ZP = 0;     // byte j of ZP: zero-row mask of column group j (bit 7-p = plane p)
 #pragma unroll
   for (int j = 0; j < NG; j++) {
     u32 Z;
     bits += encode_rows(&t[4 * j], Z);
-    ZP |= Z << (8 * j);
+    ZP |= (u64)Z << (8 * j);
   }
   // previous row of (p, j): (p, j-1), or (p-1, NG-1) for j = 0; next row: (p, j+1), or (p+1, 0)
-  constexpr u32 all = NG == 4 ? 0xffffffffu : ((1u << (8 * (NG & 3))) - 1u);
-  const u32 prevP = ((ZP << 8) & all) | (ZP >> (8 * (NG - 1) + 1));
-  const u32 nextP = (ZP >> 8) | ((ZP & 0x7fu) << (8 * (NG - 1) + 1));
-  const u32 starts = ZP & ~prevP;
-  return bits + 4u * __popc(starts) + 3u * __popc(starts & nextP);   // 4 bits per run, 7 if longer than one row
+  constexpr u64 all = NG == 8 ? ~0ull : ((1ull << (8 * (NG & 7))) - 1ull);
+  const u64 prevP = ((ZP << 8) & all) | (ZP >> (8 * (NG - 1) + 1));
+  const u64 nextP = (ZP >> 8) | ((ZP & 0x7full) << (8 * (NG - 1) + 1));
+  const u64 starts = ZP & ~prevP;
+  return bits + 4u * (u32)__popcll(starts) + 3u * (u32)__popcll(starts & nextP);   // 4 bits per run, 7 if longer than one row
 }
 
 // Run-length statistics per lane: consecutive lines of a lane with the same
@@ -592,6 +600,7 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
   switch (P->L) {
   case 32: MPC_LAUNCH(8); break;
   case 64: MPC_LAUNCH(16); break;
+  case 128: MPC_LAUNCH(32); break;
   default: return hipErrorInvalidValue;
   }
 #undef MPC_LAUNCH
@@ -608,7 +617,7 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
 // 1 when the lane-per-line kernel covers the configuration (else mpc_vpc_fast.hip runs it)
 extern "C" int mpc_vpc_lane_supported(const MpcVpcParams *P)
 {
-  if (P->L != 32 && P->L != 64) return 0;
+  if (P->L != 32 && P->L != 64 && P->L != 128) return 0;
 #define X(...) if (lane_seq_matches<__VA_ARGS__>(P)) return 1;
   MPC_LANE_SEQUENCES(X)
 #undef X

@@ -39,11 +39,10 @@ def _check_vpc(mpc, oracle, cfg, lines, expect_path=None):
     return s, sel
 
 
-@pytest.mark.parametrize("L,kernel", [(32, "lane"), (64, "lane"), (32, "quad"), (64, "quad"), (128, "quad")])
+@pytest.mark.parametrize("L,kernel", [(32, "lane"), (64, "lane"), (128, "lane"), (32, "quad"), (64, "quad"), (128, "quad")])
 def test_vpc_fast_path_probe_config(mpc, oracle, configs, traces, monkeypatch, L, kernel):
-    """Both fast kernels on the probe configuration: one lane per line (32 / 64 byte
-    lines) and L/16 lanes per line (any of the three line sizes; MPC_VPC_KERNEL=quad
-    makes a handle take it where the lane kernel would run)."""
+    """Both fast kernels on the probe configuration: one lane per line, and L/16 lanes
+    per line (MPC_VPC_KERNEL=quad makes a handle take it where the lane kernel would run)."""
     if kernel == "quad":
         monkeypatch.setenv("MPC_VPC_KERNEL", "quad")
     cfg = configs.probe_config(L)
@@ -59,7 +58,7 @@ def test_vpc_fast_path_probe_config(mpc, oracle, configs, traces, monkeypatch, L
                expect_path=mpc.MPC_PATH_VPC_LANE if kernel == "lane" else mpc.MPC_PATH_VPC_FAST)
 
 
-@pytest.mark.parametrize("L", [32, 64])
+@pytest.mark.parametrize("L", [32, 64, 128])
 def test_vpc_lane_kernel_sequences(mpc, oracle, configs, traces, L):
     """Every module sequence the lane-per-line kernel is instantiated for, with tables
     that need the byte gather (base bytes not simply the previous word) and tables that
