@@ -185,6 +185,14 @@ def main():
         probe_ms.append(a.elapsed_time(b))
     probe_gbps = n * L / (min(probe_ms[1:]) / 1e3) / 1e9
 
+    if args.algo == "BDI":
+        kernel_name = f"bdi_kernel<{L // 4}>"
+    elif ev.kernel_path == mpc.MPC_PATH_VPC_LANE:
+        kernel_name = f"vpc_lane_kernel<{L // 4}>"        # one lane per line, W = L/4 words
+    elif ev.kernel_path == mpc.MPC_PATH_VPC_FAST:
+        kernel_name = f"vpc_fast_kernel<{L // 16}>"       # L/16 lanes per line
+    else:
+        kernel_name = "vpc_generic_kernel"
     if rank == 0:
         traffic = args.traffic_bytes
         if traffic is None:
@@ -214,7 +222,7 @@ def main():
                        "sharding": f"contiguous x{world}", "compression_ratio": ratio},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "vpc_fast_kernel<4>" if (args.algo == "VPC" and L == 64) else args.algo,
+                         "kernel": kernel_name,
                          "kernel_ms_avg": avg_kern_s * 1e3, "kernel_ms_min": min(kern_ms),
                          "algorithmic_bytes_per_launch": n * L,
                          "read_probe_gbps": probe_gbps, "frac_of_read_probe": achieved / probe_gbps},
