@@ -227,6 +227,97 @@ __device__ __forceinline__ u32 bdi_check(const u32 *w)   // BDI.cpp:108-201
   return n + 8u * ((imm * (u32)D) + ((u32)B + (n - imm - 1u) * (u32)D));
 }
 
+// ---------------------------------------------------------------------------
+// Screening.  A scan that fails (some delta does not fit) with imm immediates costs
+// n + 8*(imm*D + (n-imm)*B) = n + 8L - 8*imm*(B-D) bits (BDI.cpp:196-198); with
+// imm <= n / (8*(B-D)) that is >= 8L, and CompressLine keeps only strictly smaller sizes
+// (BDI.cpp:40-66), so such a combination can never be selected and need not be
+// evaluated.  bdi_screen() finds, per lane and cheaply, combinations for which this
+// certainly holds (value 0 is the base, one of values 1..3 is a witness whose delta does
+// not fit, the immediates are counted exactly); the kernel skips a combination when the
+// test holds for every active lane of the wave and runs the exact scan otherwise.
+// ---------------------------------------------------------------------------
+
+// class k of a signed 64-bit value x = (hi, lo):  reduceSign(x) <= 2^(8D)-1  <=>  k <= 8D
+__device__ __forceinline__ u32 bdi_class64(u32 hi, u32 lo)
+{
+  const u32 sx = (u32)((int)hi >> 31);
+  const u32 y = lo ^ sx;                                   // magnitude bits below the sign
+  const u32 k = 32u - (u32)__clz((int)y) - sx;             // + 1 sign bit for negative values
+  const bool out = (hi != sx) || ((lo & hi) == 0xffffffffu);   // beyond 32 bits, or x == -1
+  return out ? 64u : k;
+}
+
+// the same for base - v of two zero-extended 32-bit values
+__device__ __forceinline__ u32 bdi_class_delta32(u32 base, u32 v)
+{
+  const u32 d = base - v;
+  const u32 sx = base < v ? 0xffffffffu : 0u;
+  const u32 y = d ^ sx;
+  const u32 k = 32u - (u32)__clz((int)y) - sx;
+  return (sx && y == 0u) ? 64u : k;                       // base - v == -1 never fits
+}
+
+template <int NW>
+__device__ __forceinline__ u32 bdi_screen(const u32 *w)    // bit c: combination c (B8D1, B8D2, B8D4, B4D1, B4D2, B2D1) cannot be selected
+{
+  u32 ns = 0;
+  {   // 8-byte bases: a value can only be an immediate (any D) when its high word is 0 or -1
+    constexpr int n = NW / 2;
+    u32 cnt = 0;
+#pragma unroll
+    for (int i = 0; i < n; i++) cnt += (w[2 * i + 1] + 1u <= 1u) ? 1u : 0u;
+    u32 kd = 0;   // worst delta class of values 1..3 against value 0 (the base when there is no immediate)
+#pragma unroll
+    for (int i = 1; i < (n < 4 ? n : 4); i++) {
+      const u32 dlo = w[0] - w[2 * i];
+      const u32 dhi = w[1] - w[2 * i + 1] - (w[0] < w[2 * i] ? 1u : 0u);
+      kd = max(kd, bdi_class64(dhi, dlo));
+    }
+    const bool noimm = cnt == 0;
+    ns |= (noimm && kd > 8u) ? 1u : 0u;
+    ns |= (noimm && kd > 16u) ? 2u : 0u;
+    ns |= (noimm && kd > 32u) ? 4u : 0u;
+  }
+  {   // 4-byte bases
+    constexpr int n = NW;
+    u32 i1 = 0, i2 = 0;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+      i1 += w[i] <= 0xffu ? 1u : 0u;
+      i2 += w[i] <= 0xffffu ? 1u : 0u;
+    }
+    bool f1 = false, f2 = false;
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+      const u32 kd = bdi_class_delta32(w[0], w[i]);
+      f1 = f1 || (w[i] > 0xffu && kd > 8u);
+      f2 = f2 || (w[i] > 0xffffu && kd > 16u);
+    }
+    ns |= (w[0] > 0xffu && f1 && i1 <= (u32)(n / 24)) ? 8u : 0u;
+    ns |= (w[0] > 0xffffu && f2 && i2 <= (u32)(n / 16)) ? 16u : 0u;
+  }
+  {   // 2-byte bases: immediates are the 16-bit values with a zero high byte
+    constexpr int n = 2 * NW;
+    u32 nz = 0;   // values with a non-zero high byte
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      const u32 x = w[i] & 0xff00ff00u;
+      nz += (u32)__popc((((x & 0x7f007f00u) + 0x7f007f00u) | x) & 0x80008000u);
+    }
+    const u32 v0 = w[0] & 0xffffu;
+    bool f = false;
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+      const u32 v = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+      const u32 t = v0 - v + 128u;      // delta in [0,255] or [-128,-2]  <=>  t in [128,383] or [0,126]
+      f = f || (v > 0xffu && !(t <= 383u && t != 127u));
+    }
+    ns |= (v0 > 0xffu && f && (u32)n - nz <= (u32)(n / 8)) ? 32u : 0u;
+  }
+  return ns;
+}
+
 template <int NW>   // words per line
 __global__ void __launch_bounds__(256)
 bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ sizes_out,
@@ -261,13 +352,15 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
       best = 64;
       select = 1;
     } else {
+      // combinations that cannot be selected on any active lane of the wave are skipped
+      const u32 ns = bdi_screen<NW>(w);
       u32 c;
-      c = bdi_check<8, 1, NW>(w); if (best > c) { best = c; select = 2; }
-      c = bdi_check<8, 2, NW>(w); if (best > c) { best = c; select = 3; }
-      c = bdi_check<8, 4, NW>(w); if (best > c) { best = c; select = 4; }
-      c = bdi_check<4, 1, NW>(w); if (best > c) { best = c; select = 5; }
-      c = bdi_check<4, 2, NW>(w); if (best > c) { best = c; select = 6; }
-      c = bdi_check<2, 1, NW>(w); if (best > c) { best = c; select = 7; }
+      if (__ballot(!(ns & 1u))) { c = bdi_check<8, 1, NW>(w); if (best > c) { best = c; select = 2; } }
+      if (__ballot(!(ns & 2u))) { c = bdi_check<8, 2, NW>(w); if (best > c) { best = c; select = 3; } }
+      if (__ballot(!(ns & 4u))) { c = bdi_check<8, 4, NW>(w); if (best > c) { best = c; select = 4; } }
+      if (__ballot(!(ns & 8u))) { c = bdi_check<4, 1, NW>(w); if (best > c) { best = c; select = 5; } }
+      if (__ballot(!(ns & 16u))) { c = bdi_check<4, 2, NW>(w); if (best > c) { best = c; select = 6; } }
+      if (__ballot(!(ns & 32u))) { c = bdi_check<2, 1, NW>(w); if (best > c) { best = c; select = 7; } }
       if (best == uncomp) select = 8;
     }
     const u32 size = best + 4u;

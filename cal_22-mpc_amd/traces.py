@@ -93,6 +93,64 @@ def counters_u32(n_lines: int, line_size: int = 32, first_line: int = 0) -> np.n
     return (idx % 251).astype("<u4").view(np.uint8).reshape(n_lines, line_size)
 
 
+def bdi_screen_stress(n_lines: int, line_size: int = 64, seed: int = 4242) -> np.ndarray:
+    """Lines around the thresholds of the BDI kernel's screening test: for a base
+    size B the line is random B-byte values (every scan fails) with 0 .. T+2
+    immediates for each delta size (T = n / (8 (B - D)), the largest count for
+    which a failed scan still costs >= 8 L bits), immediates placed at value 0, at
+    values 1..3 (the witness positions) or anywhere, negative / sign-extended
+    8-byte immediates, lines whose only misfitting delta lies beyond value 3, and
+    deltas of exactly -1.  Interleaved with plain random lines so that waves
+    hold both kinds."""
+    rng = np.random.default_rng(seed)
+    L = line_size
+    out = rng.integers(0, 256, (n_lines, L), dtype=np.uint8)
+    for i in range(n_lines):
+        k = i % 8
+        if k >= 5:
+            continue                                   # plain random line
+        B = (2, 4, 8)[(i // 8) % 3]
+        n = L // B
+        bits = 8 * B
+        D = {2: (1,), 4: (1, 2), 8: (1, 2, 4)}[B]
+        d_sz = D[(i // 24) % len(D)]
+        T = n // (8 * (B - d_sz))
+        vals = [int(x) for x in rng.integers(1 << (bits - 2), 1 << (bits - 1), n, dtype=np.uint64)]
+        if k == 0 or k == 1:
+            # c immediates for delta size d_sz at chosen positions
+            c = int(rng.integers(0, T + 3))
+            where = (i // 72) % 3
+            pos = list(rng.permutation(n)[:c])
+            if where == 0 and c:
+                pos[0] = 0
+            elif where == 1 and c:
+                pos[0] = int(rng.integers(1, min(4, n)))
+            for p_ in pos:
+                v = int(rng.integers(0, 1 << (8 * d_sz)))
+                if B == 8 and k == 1:
+                    v = (-int(rng.integers(2, 1 << (8 * d_sz - 1)))) % (1 << 64)   # negative immediate
+                vals[int(p_)] = v
+        elif k == 2:
+            # all deltas fit except one beyond the witness positions
+            base = vals[0]
+            vals = [(base + int(x)) % (1 << bits) for x in rng.integers(0, 1 << (8 * d_sz - 1), n)]
+            vals[0] = base
+            if n > 4:
+                vals[int(rng.integers(4, n))] = int(rng.integers(1 << (bits - 2), 1 << (bits - 1), dtype=np.uint64))
+        elif k == 3:
+            # everything fits (the combination is selected), with a -1 delta in every other such line
+            base = vals[0]
+            vals = [(base + int(x)) % (1 << bits) for x in rng.integers(0, 1 << (8 * d_sz - 1), n)]
+            vals[0] = base
+            if (i // 8) % 2 and n > 1:
+                vals[int(rng.integers(1, n))] = (base + 1) % (1 << bits)
+        else:
+            # value 0 immediate, the rest random (base is a later value)
+            vals[0] = int(rng.integers(0, 1 << (8 * d_sz)))
+        out[i] = np.array(vals, dtype=np.uint64).astype({2: "<u2", 4: "<u4", 8: "<u8"}[B]).view(np.uint8)
+    return out
+
+
 def bdi_stress(n_lines: int, line_size: int = 64, seed: int = 777) -> np.ndarray:
     """Lines that exercise every BDI mode (reference ``BDI.cpp:6-74``): zeros,
     8-byte repeats, each (base, delta) combination, deltas of exactly -1

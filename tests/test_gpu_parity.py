@@ -190,7 +190,8 @@ def test_generic_and_fast_agree(mpc, configs, traces):
 @pytest.mark.parametrize("L", [32, 64, 128])
 def test_bdi(mpc, oracle, traces, L):
     lines = np.concatenate([traces.bdi_stress(5600, L), traces.random_u32(500, L), traces.zeros(30, L),
-                            traces.structured(2400, L), traces.pointers_u64(1000, L), traces.mixed(1000, L)])
+                            traces.structured(2400, L), traces.pointers_u64(1000, L), traces.mixed(1000, L),
+                            traces.bdi_screen_stress(14400, L), traces.bdi_screen_stress(7200, L, seed=9)[::-1]])
     ev = mpc.BDI(L)
     o = oracle.BdiOracle(L)
     s_ref, sel_ref = o.compress(lines)
