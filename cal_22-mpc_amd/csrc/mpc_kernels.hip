@@ -229,13 +229,15 @@ __device__ __forceinline__ u32 bdi_check(const u32 *w)   // BDI.cpp:108-201
 
 // ---------------------------------------------------------------------------
 // Screening.  A scan that fails (some delta does not fit) with imm immediates costs
-// n + 8*(imm*D + (n-imm)*B) = n + 8L - 8*imm*(B-D) bits (BDI.cpp:196-198); with
-// imm <= n / (8*(B-D)) that is >= 8L, and CompressLine keeps only strictly smaller sizes
-// (BDI.cpp:40-66), so such a combination can never be selected and need not be
-// evaluated.  bdi_screen() finds, per lane and cheaply, combinations for which this
-// certainly holds (value 0 is the base, one of values 1..3 is a witness whose delta does
-// not fit, the immediates are counted exactly); the kernel skips a combination when the
-// test holds for every active lane of the wave and runs the exact scan otherwise.
+// n + 8*(imm*D + (n-imm)*B) = n + 8L - 8*imm*(B-D) bits (BDI.cpp:196-198), and
+// CompressLine keeps only strictly smaller sizes (BDI.cpp:40-66): when that cost is
+// not below the best size found so far the combination cannot be selected and need not
+// be evaluated.  bdi_screen() finds, per lane and cheaply, combinations whose scan
+// certainly fails (value 0 is the base, one of values 1..3 is a non-immediate witness
+// whose delta does not fit) and a floor of the failed cost from an upper bound of the
+// immediates (exact for 4- and 2-byte bases); the kernel skips a combination when
+// "fails and floor >= best" holds on every active lane of the wave and runs the exact
+// scan otherwise.
 // ---------------------------------------------------------------------------
 
 // class k of a signed 64-bit value x = (hi, lo):  reduceSign(x) <= 2^(8D)-1  <=>  k <= 8D
@@ -258,28 +260,41 @@ __device__ __forceinline__ u32 bdi_class_delta32(u32 base, u32 v)
   return (sx && y == 0u) ? 64u : k;                       // base - v == -1 never fits
 }
 
+struct BdiScreen {
+  u32 fails;      // bit c: the scan of combination c (B8D1, B8D2, B8D4, B4D1, B4D2, B2D1) certainly fails
+  u32 floor[6];   // if it fails it costs at least this many bits
+};
+
 template <int NW>
-__device__ __forceinline__ u32 bdi_screen(const u32 *w)    // bit c: combination c (B8D1, B8D2, B8D4, B4D1, B4D2, B2D1) cannot be selected
+__device__ __forceinline__ BdiScreen bdi_screen(const u32 *w)
 {
-  u32 ns = 0;
+  constexpr u32 L8 = 32u * NW;     // 8 * L
+  BdiScreen sc;
+  sc.fails = 0;
   {   // 8-byte bases: a value can only be an immediate (any D) when its high word is 0 or -1
     constexpr int n = NW / 2;
-    u32 cnt = 0;
+    u32 cnt = 0;   // upper bound of the immediates of every D
 #pragma unroll
     for (int i = 0; i < n; i++) cnt += (w[2 * i + 1] + 1u <= 1u) ? 1u : 0u;
-    u32 kd = 0;   // worst delta class of values 1..3 against value 0 (the base when there is no immediate)
+    // value 0 is the base when it cannot be an immediate; witnesses: values 1..3 that cannot be
+    // immediates either and whose delta does not fit
+    const bool base0 = w[1] + 1u > 1u;
+    u32 kd = 0;
 #pragma unroll
     for (int i = 1; i < (n < 4 ? n : 4); i++) {
       const u32 dlo = w[0] - w[2 * i];
       const u32 dhi = w[1] - w[2 * i + 1] - (w[0] < w[2 * i] ? 1u : 0u);
-      kd = max(kd, bdi_class64(dhi, dlo));
+      const u32 k = bdi_class64(dhi, dlo);
+      kd = max(kd, (w[2 * i + 1] + 1u > 1u) ? k : 0u);
     }
-    const bool noimm = cnt == 0;
-    ns |= (noimm && kd > 8u) ? 1u : 0u;
-    ns |= (noimm && kd > 16u) ? 2u : 0u;
-    ns |= (noimm && kd > 32u) ? 4u : 0u;
+    sc.fails |= (base0 && kd > 8u) ? 1u : 0u;
+    sc.fails |= (base0 && kd > 16u) ? 2u : 0u;
+    sc.fails |= (base0 && kd > 32u) ? 4u : 0u;
+    sc.floor[0] = (u32)n + L8 - 8u * 7u * cnt;
+    sc.floor[1] = (u32)n + L8 - 8u * 6u * cnt;
+    sc.floor[2] = (u32)n + L8 - 8u * 4u * cnt;
   }
-  {   // 4-byte bases
+  {   // 4-byte bases: exact immediate counts
     constexpr int n = NW;
     u32 i1 = 0, i2 = 0;
 #pragma unroll
@@ -294,8 +309,10 @@ __device__ __forceinline__ u32 bdi_screen(const u32 *w)    // bit c: combination
       f1 = f1 || (w[i] > 0xffu && kd > 8u);
       f2 = f2 || (w[i] > 0xffffu && kd > 16u);
     }
-    ns |= (w[0] > 0xffu && f1 && i1 <= (u32)(n / 24)) ? 8u : 0u;
-    ns |= (w[0] > 0xffffu && f2 && i2 <= (u32)(n / 16)) ? 16u : 0u;
+    sc.fails |= (w[0] > 0xffu && f1) ? 8u : 0u;
+    sc.fails |= (w[0] > 0xffffu && f2) ? 16u : 0u;
+    sc.floor[3] = (u32)n + L8 - 8u * 3u * i1;
+    sc.floor[4] = (u32)n + L8 - 8u * 2u * i2;
   }
   {   // 2-byte bases: immediates are the 16-bit values with a zero high byte
     constexpr int n = 2 * NW;
@@ -313,9 +330,10 @@ __device__ __forceinline__ u32 bdi_screen(const u32 *w)    // bit c: combination
       const u32 t = v0 - v + 128u;      // delta in [0,255] or [-128,-2]  <=>  t in [128,383] or [0,126]
       f = f || (v > 0xffu && !(t <= 383u && t != 127u));
     }
-    ns |= (v0 > 0xffu && f && (u32)n - nz <= (u32)(n / 8)) ? 32u : 0u;
+    sc.fails |= (v0 > 0xffu && f) ? 32u : 0u;
+    sc.floor[5] = (u32)n + L8 - 8u * ((u32)n - nz);
   }
-  return ns;
+  return sc;
 }
 
 template <int NW>   // words per line
@@ -352,15 +370,22 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
       best = 64;
       select = 1;
     } else {
-      // combinations that cannot be selected on any active lane of the wave are skipped
-      const u32 ns = bdi_screen<NW>(w);
+      // a combination whose scan certainly fails at a cost >= the lane's best so far cannot be
+      // selected; it is skipped when that holds on every active lane of the wave
+      const BdiScreen sc = bdi_screen<NW>(w);
       u32 c;
-      if (__ballot(!(ns & 1u))) { c = bdi_check<8, 1, NW>(w); if (best > c) { best = c; select = 2; } }
-      if (__ballot(!(ns & 2u))) { c = bdi_check<8, 2, NW>(w); if (best > c) { best = c; select = 3; } }
-      if (__ballot(!(ns & 4u))) { c = bdi_check<8, 4, NW>(w); if (best > c) { best = c; select = 4; } }
-      if (__ballot(!(ns & 8u))) { c = bdi_check<4, 1, NW>(w); if (best > c) { best = c; select = 5; } }
-      if (__ballot(!(ns & 16u))) { c = bdi_check<4, 2, NW>(w); if (best > c) { best = c; select = 6; } }
-      if (__ballot(!(ns & 32u))) { c = bdi_check<2, 1, NW>(w); if (best > c) { best = c; select = 7; } }
+#define MPC_BDI_TRY(IDX, B, D)                                                      \
+      if (__ballot(!((sc.fails >> IDX) & 1u) || sc.floor[IDX] < best)) {            \
+        c = bdi_check<B, D, NW>(w);                                                 \
+        if (best > c) { best = c; select = IDX + 2; }                               \
+      }
+      MPC_BDI_TRY(0, 8, 1)
+      MPC_BDI_TRY(1, 8, 2)
+      MPC_BDI_TRY(2, 8, 4)
+      MPC_BDI_TRY(3, 4, 1)
+      MPC_BDI_TRY(4, 4, 2)
+      MPC_BDI_TRY(5, 2, 1)
+#undef MPC_BDI_TRY
       if (best == uncomp) select = 8;
     }
     const u32 size = best + 4u;
