@@ -179,7 +179,7 @@ int create_vpc_from_text(const std::string &text, int device, mpc_handle **out)
 // Workgroups per CU of the grid-stride VPC kernels.  4-5 are resident; a grid of 32 per CU
 // lets CUs that finish early pick up more work (same-box A/B against 8 per CU: random -3.5 %,
 // mixed -5 %, 128-byte lines -9 %; all-zero traces +3 %).
-constexpr int kVpcWgPerCu = 32;
+constexpr int kWgPerCu = 32;
 
 int grid_for(const mpc_handle *h, u64 work_items, int block, int per_cu)
 {
@@ -197,12 +197,12 @@ int launch(mpc_handle *h, const void *d_lines, u64 n, uint16_t *d_sizes, int8_t 
   if (n == 0) return MPC_OK;
   hipError_t e;
   if (h->algorithm == 1) {
-    e = mpc_launch_bdi(d_lines, n, h->L, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, 8), s);
+    e = mpc_launch_bdi(d_lines, n, h->L, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
   } else if (h->plan.fast && h->lane_kernel) {
-    e = mpc_launch_vpc_lane(d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kVpcWgPerCu), s);
+    e = mpc_launch_vpc_lane(d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
   } else if (h->plan.fast) {
     const u64 chunks = n * (u64)(h->L / 16);
-    e = mpc_launch_vpc_fast(d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw, grid_for(h, chunks, 256, kVpcWgPerCu), s);
+    e = mpc_launch_vpc_fast(d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw, grid_for(h, chunks, 256, kWgPerCu), s);
   } else {
     e = mpc_launch_vpc_generic(d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw, grid_for(h, n, 128, 8), s);
   }
