@@ -334,9 +334,11 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     // c1 split into its low-7-bit and MSB parts (lane-per-line kernel, WeightBase residue)
     for (size_t w = 0; w < c1.size(); w++) plan.tab.push_back(c1[w] & 0x7f7f7f7fu);
     for (size_t w = 0; w < c1.size(); w++) plan.tab.push_back(c1[w] & 0x80808080u);
+    // periodic tables: words 1.. all use "the same byte of the previous word" with identical masks /
+    // constants, so the kernel needs neither the byte gather nor per-word table entries
     f.prev_word = 1;
     for (size_t w = 1; w < sel.size(); w++)
-      if (sel[w] != 0x03020100u) f.prev_word = 0;
+      if (sel[w] != 0x03020100u || c1[w] != c1[1] || c2[w] != c2[1]) f.prev_word = 0;
   }
   while (plan.tab.size() % 4) plan.tab.push_back(0);
   if (plan.tab.empty()) plan.tab.assign(4, 0);

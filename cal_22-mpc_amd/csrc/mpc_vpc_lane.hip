@@ -23,8 +23,9 @@
 
 namespace {
 
-// lane-kernel predictor kinds: MPC_FK_* plus LK_PW when every base byte of words 1.. is the
-// same byte of the previous word (MpcFastModule::prev_word): no v_perm_b32 needed
+// lane-kernel predictor kinds: MPC_FK_* plus LK_PW for periodic tables (MpcFastModule::prev_word):
+// every base byte of words 1.. is the same byte of the previous word and the table entries of
+// words 1.. are identical -- no v_perm_b32, two table entries (word 0, the other words)
 constexpr int LK_PW = 8;
 __device__ __host__ constexpr int lk_base(int kind) { return kind & 7; }
 
@@ -82,15 +83,16 @@ template <int W, int KIND, bool FULL = true>
 __device__ __forceinline__ u32 window_residue(const Lane<W> &c, int e, const u32 *__restrict__ t, const MpcFastModule &fm)
 {
   const u32 b = window_base<W, KIND>(c, e, t);
+  const int k = (KIND & LK_PW) ? (e ? 1 : 0) : e;     // table entry of word e
   if constexpr (lk_base(KIND) == MPC_FK_WEIGHT) {
     // class 1 unshifted (mask c1), class 2 shifted right (mask c2, MSBs clear): the low 7 bits
     // and the MSB of the predicted byte come from the pre-split masks t[3W..], t[4W..]
-    const u32 p7 = ((b >> fm.rs2) & t[2 * W + e]) | (b & t[3 * W + e]);
+    const u32 p7 = ((b >> fm.rs2) & t[2 * W + k]) | (b & t[3 * W + k]);
     const u32 sub = (c.x[e] | H80) - p7;
-    const u32 w = c.x[e] ^ (b & t[4 * W + e]);          // bit 7: line ^ predicted
+    const u32 w = c.x[e] ^ (b & t[4 * W + k]);          // bit 7: line ^ predicted
     return FULL ? (sub ^ (~w & H80)) : (sub ^ ~w);
   } else {
-    const u32 pred = window_predict<lk_base(KIND)>(b, t[W + e], t[2 * W + e], fm);
+    const u32 pred = window_predict<lk_base(KIND)>(b, t[W + k], t[2 * W + k], fm);
     return FULL ? bsub(c.x[e], pred) : msb_of_bsub(c.x[e], pred);
   }
 }
@@ -434,10 +436,12 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
 #pragma unroll
       for (int e = 0; e < W; e++) t[e] = best.r[e] ^ ((best.r[e] >> 1) & (e == 0 ? 0x7f7f7f00u : L7F));
     } else {
+      // both flavours, selected per lane with bit masks (no divergence)
+      const u32 cx7 = best.cx ? L7F : 0u, ncx = best.cx ? 0u : ~0u;
 #pragma unroll
       for (int e = 0; e < W; e++) {
-        const u32 m = (best.r[e] >> 7) & 0x01010101u;
-        const u32 f = best.cx ? ((best.r[e] >> 1) & L7F) : ((m << 7) - m);
+        const u32 a = best.r[e] & H80;
+        const u32 f = ((best.r[e] >> 1) & cx7) | ((a - (a >> 7)) & ncx);
         t[e] = best.r[e] ^ (e == 0 ? (f & 0xffffff00u) : f);
       }
     }
@@ -578,9 +582,10 @@ bool lane_seq_matches(const MpcVpcParams *P)
   const int kinds[n] = {KINDS...};
   if (P->n_pred != n) return false;
   for (int q = 0; q < n; q++) {
+    // a periodic-table instantiation (LK_PW) needs the flag; the plain one runs any table
     const MpcFastModule &f = P->fm[q];
-    const bool window = f.kind == MPC_FK_DIFF || f.kind == MPC_FK_WEIGHT || f.kind == MPC_FK_WEIGHT2;
-    if ((f.kind | ((window && f.prev_word) ? LK_PW : 0)) != kinds[q]) return false;
+    if (f.kind != lk_base(kinds[q])) return false;
+    if ((kinds[q] & LK_PW) && !f.prev_word) return false;
   }
   return true;
 }
