@@ -187,10 +187,8 @@ def main():
 
     if args.algo == "BDI":
         kernel_name = f"bdi_kernel<{L // 4}>"
-    elif ev.kernel_path == mpc.MPC_PATH_VPC_LANE:
-        kernel_name = f"vpc_lane_kernel<{L // 4}>"        # one lane per line, W = L/4 words
     elif ev.kernel_path == mpc.MPC_PATH_VPC_FAST:
-        kernel_name = f"vpc_fast_kernel<{L // 16}>"       # L/16 lanes per line
+        kernel_name = f"vpc_lane_kernel<{L // 4}>"        # one lane per line, W = L/4 words
     else:
         kernel_name = "vpc_generic_kernel"
     if rank == 0:

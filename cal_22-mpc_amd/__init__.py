@@ -23,7 +23,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPC_HIP_LIB") or os.path.join(HERE, "libmpc_hip.so")   # override: development builds only
 
-MPC_PATH_VPC_FAST, MPC_PATH_VPC_GENERIC, MPC_PATH_BDI, MPC_PATH_VPC_LANE = 1, 2, 3, 4
+MPC_PATH_VPC_FAST, MPC_PATH_VPC_GENERIC, MPC_PATH_BDI = 1, 2, 3
 SYNTH_KINDS = {"zeros": 0, "random_u32": 1, "sine_f32": 2, "mixed": 3, "pointers_u64": 4}
 
 

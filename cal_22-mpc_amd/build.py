@@ -42,8 +42,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and _newer(LIB, deps):
         return LIB
     cmd = [HIPCC, *FLAGS, "-shared", "-o", LIB,
-           os.path.join(CSRC, "mpc_vpc_fast.hip"), os.path.join(CSRC, "mpc_vpc_lane.hip"),
-           os.path.join(CSRC, "mpc_kernels.hip"),
+           os.path.join(CSRC, "mpc_vpc_lane.hip"), os.path.join(CSRC, "mpc_kernels.hip"),
            os.path.join(CSRC, "mpc_capi.hip")]
     if verbose:
         print(" ".join(cmd))

@@ -18,14 +18,12 @@
 typedef unsigned long long u64;
 
 extern "C" {
-hipError_t mpc_launch_vpc_fast(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
 hipError_t mpc_launch_vpc_generic(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
 hipError_t mpc_launch_bdi(const void *, u64, int, uint16_t *, int8_t *, u64 *, int, hipStream_t);
 hipError_t mpc_launch_synth(void *, u64, unsigned, int, u64, u64, const uint32_t *, hipStream_t);
 hipError_t mpc_launch_read_probe(const void *, u64, uint32_t *, int, hipStream_t);
 hipError_t mpc_launch_vpc_lane(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
-int mpc_vpc_lane_supported(const MpcVpcParams *);
-size_t mpc_vpc_fast_smem(const MpcVpcParams *);
+size_t mpc_vpc_lane_smem(const MpcVpcParams *);
 size_t mpc_vpc_generic_smem(const MpcVpcParams *);
 }
 
@@ -56,7 +54,6 @@ struct mpc_handle {
   int device = 0;
   int L = 0;
   int num_cus = 256;
-  bool lane_kernel = false;      // fast path: one lane per line (mpc_vpc_lane.hip) instead of L/16 lanes per line
   mpc::VpcConfig cfg;
   mpc::VpcPlan plan;
   hipStream_t stream = nullptr;
@@ -157,11 +154,8 @@ int create_vpc_from_text(const std::string &text, int device, mpc_handle **out)
   if (rc == MPC_OK) {
     h->plan.params.tab = h->d_tab;
     h->plan.params.gtab = h->d_gtab;
-    // MPC_VPC_KERNEL=quad is a development switch for same-box A/B timing of the two fast kernels
-    const char *kv = getenv("MPC_VPC_KERNEL");
-    h->lane_kernel = h->plan.fast && mpc_vpc_lane_supported(&h->plan.params) && !(kv && std::string(kv) == "quad");
     // the statistics accumulators of a workgroup live in LDS
-    const size_t smem = h->plan.fast ? mpc_vpc_fast_smem(&h->plan.params) : mpc_vpc_generic_smem(&h->plan.params);
+    const size_t smem = h->plan.fast ? mpc_vpc_lane_smem(&h->plan.params) : mpc_vpc_generic_smem(&h->plan.params);
     if (smem > 150 * 1024) {
       g_create_error = "histogram does not fit the 160 KiB LDS (too many clusters x bins)";
       rc = MPC_E_INVAL;
@@ -198,11 +192,8 @@ int launch(mpc_handle *h, const void *d_lines, u64 n, uint16_t *d_sizes, int8_t 
   hipError_t e;
   if (h->algorithm == 1) {
     e = mpc_launch_bdi(d_lines, n, h->L, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
-  } else if (h->plan.fast && h->lane_kernel) {
-    e = mpc_launch_vpc_lane(d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
   } else if (h->plan.fast) {
-    const u64 chunks = n * (u64)(h->L / 16);
-    e = mpc_launch_vpc_fast(d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw, grid_for(h, chunks, 256, kWgPerCu), s);
+    e = mpc_launch_vpc_lane(d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
   } else {
     e = mpc_launch_vpc_generic(d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw, grid_for(h, n, 128, 8), s);
   }
@@ -441,7 +432,7 @@ int mpc_get_info(const mpc_handle *h, mpc_info *info)
   info->num_modules = h->algorithm == 0 ? h->cfg.M : 0;
   info->num_clusters = h->algorithm == 0 ? h->cfg.M + 1 : 9;
   info->hist_bins = h->algorithm == 0 ? h->cfg.hist_bins : 0;
-  info->kernel_path = h->algorithm == 1 ? MPC_PATH_BDI : (h->plan.fast ? (h->lane_kernel ? MPC_PATH_VPC_LANE : MPC_PATH_VPC_FAST) : MPC_PATH_VPC_GENERIC);
+  info->kernel_path = h->algorithm == 1 ? MPC_PATH_BDI : (h->plan.fast ? MPC_PATH_VPC_FAST : MPC_PATH_VPC_GENERIC);
   info->device = h->device;
   info->stats_len = h->stats_len;
   return MPC_OK;

@@ -215,20 +215,6 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
   P.has_aws = cfg.has_aws ? 1 : 0;
   P.hist_bins = cfg.hist_bins;
   for (int k = 0; k <= cfg.M; k++) P.enc_bits[k] = cfg.enc_bits[(size_t)k];
-  {
-    // Smallest number c of rows that certainly cost 17 bits (FPCModule.h:55) for which the
-    // common encoder cannot get below 8*L bits whatever the other R-c rows are: their
-    // cheapest arrangement is one run of zero rows (7 bits, or 4 for a single row).
-    const int R = (8 * L) / 16;
-    int c = R + 1;
-    for (int k = 0; k <= R; k++) {
-      const int rest = R - k;
-      const int floor_bits = 17 * k + (rest == 0 ? 0 : (rest == 1 ? 4 : 7));
-      if (floor_bits >= 8 * L) { c = k; break; }
-    }
-    P.cert_min17 = c;
-  }
-
   // ---- generic tables (always built: the generic kernel handles anything) ----
   plan.gtab.clear();
   for (int q = 0; q < cfg.n_pred; q++) {

@@ -51,7 +51,7 @@ struct MpcVpcParams {
   int32_t start;        /* module index of the first PredComp module (1 or 2) */
   int32_t has_aws;      /* module 1 is AllWordSame */
   int32_t hist_bins;    /* bins per cluster */
-  int32_t cert_min17;   /* >= this many certain 17-bit rows => the encoding cannot beat 8*L bits */
+  int32_t reserved0;
   int32_t tab_words;    /* number of dwords in tab */
   int32_t enc_bits[MPC_MAX_MODULES + 1];  /* index cluster+1 */
   struct MpcFastModule fm[MPC_MAX_PRED];

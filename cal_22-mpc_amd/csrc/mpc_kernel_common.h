@@ -1,6 +1,5 @@
-// mpc_kernel_common.h -- device helpers shared by the gfx950 kernels: DPP cross-lane
-// primitives for the lanes that hold one line, SWAR byte arithmetic on 32-bit words,
-// per-workgroup LDS statistics.
+// mpc_kernel_common.h -- device helpers shared by the gfx950 kernels: SWAR byte arithmetic
+// on 32-bit words, the common encoder's row classification, per-workgroup LDS statistics.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,64 +11,6 @@ typedef uint32_t u32;
 
 #define H80 0x80808080u
 #define L7F 0x7f7f7f7fu
-
-// ---------------------------------------------------------------------------
-// DPP helpers
-// ---------------------------------------------------------------------------
-#define QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
-#define DPP_ROW_SHL(n) (0x100 + (n))
-#define DPP_ROW_SHR(n) (0x110 + (n))
-#define DPP_ROW_HALF_MIRROR 0x141
-
-template <int CTRL>
-__device__ __forceinline__ u32 dpp(u32 v)
-{
-  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-}
-
-// Cross-lane operations inside the LPL lanes that hold one line.
-template <int LPL> struct Grp;
-
-template <> struct Grp<4> {
-  static __device__ __forceinline__ u32 prev(u32 v) { return dpp<QP(0, 0, 1, 2)>(v); }   // lane g-1 (g=0: self)
-  static __device__ __forceinline__ u32 next(u32 v) { return dpp<QP(1, 2, 3, 3)>(v); }   // lane g+1 (last: self)
-  static __device__ __forceinline__ u32 first(u32 v) { return dpp<QP(0, 0, 0, 0)>(v); }
-  static __device__ __forceinline__ u32 last(u32 v) { return dpp<QP(3, 3, 3, 3)>(v); }
-  static __device__ __forceinline__ u32 red_or(u32 v) { v |= dpp<QP(1, 0, 3, 2)>(v); v |= dpp<QP(2, 3, 0, 1)>(v); return v; }
-  static __device__ __forceinline__ u32 red_add(u32 v) { v += dpp<QP(1, 0, 3, 2)>(v); v += dpp<QP(2, 3, 0, 1)>(v); return v; }
-  static __device__ __forceinline__ u32 red_min(u32 v) { v = min(v, dpp<QP(1, 0, 3, 2)>(v)); v = min(v, dpp<QP(2, 3, 0, 1)>(v)); return v; }
-};
-
-template <> struct Grp<2> {
-  static __device__ __forceinline__ u32 prev(u32 v) { return dpp<QP(0, 0, 2, 2)>(v); }
-  static __device__ __forceinline__ u32 next(u32 v) { return dpp<QP(1, 1, 3, 3)>(v); }
-  static __device__ __forceinline__ u32 first(u32 v) { return dpp<QP(0, 0, 2, 2)>(v); }
-  static __device__ __forceinline__ u32 last(u32 v) { return dpp<QP(1, 1, 3, 3)>(v); }
-  static __device__ __forceinline__ u32 red_or(u32 v) { return v | dpp<QP(1, 0, 3, 2)>(v); }
-  static __device__ __forceinline__ u32 red_add(u32 v) { return v + dpp<QP(1, 0, 3, 2)>(v); }
-  static __device__ __forceinline__ u32 red_min(u32 v) { return min(v, dpp<QP(1, 0, 3, 2)>(v)); }
-};
-
-template <> struct Grp<8> {
-  // groups are the aligned 8-lane halves of a 16-lane DPP row
-  static __device__ __forceinline__ u32 prev(u32 v) { return dpp<DPP_ROW_SHR(1)>(v); }   // g=0: other group / 0 (caller masks)
-  static __device__ __forceinline__ u32 next(u32 v) { return dpp<DPP_ROW_SHL(1)>(v); }   // g=7: other group / 0 (caller masks)
-  static __device__ __forceinline__ u32 first(u32 v)
-  {
-    u32 q = dpp<QP(0, 0, 0, 0)>(v);          // lane 0 of each quad
-    u32 s = dpp<DPP_ROW_SHR(4)>(q);          // the quad below
-    return (threadIdx.x & 4) ? s : q;
-  }
-  static __device__ __forceinline__ u32 last(u32 v)
-  {
-    u32 q = dpp<QP(3, 3, 3, 3)>(v);
-    u32 s = dpp<DPP_ROW_SHL(4)>(q);
-    return (threadIdx.x & 4) ? q : s;
-  }
-  static __device__ __forceinline__ u32 red_or(u32 v) { v |= dpp<QP(1, 0, 3, 2)>(v); v |= dpp<QP(2, 3, 0, 1)>(v); v |= dpp<DPP_ROW_HALF_MIRROR>(v); return v; }
-  static __device__ __forceinline__ u32 red_add(u32 v) { v += dpp<QP(1, 0, 3, 2)>(v); v += dpp<QP(2, 3, 0, 1)>(v); v += dpp<DPP_ROW_HALF_MIRROR>(v); return v; }
-  static __device__ __forceinline__ u32 red_min(u32 v) { v = min(v, dpp<QP(1, 0, 3, 2)>(v)); v = min(v, dpp<QP(2, 3, 0, 1)>(v)); v = min(v, dpp<DPP_ROW_HALF_MIRROR>(v)); return v; }
-};
 
 // ---------------------------------------------------------------------------
 // SWAR byte arithmetic on 32-bit words
@@ -132,21 +73,6 @@ __device__ __forceinline__ u32 encode_rows(const u32 t[4], u32 &zero_mask)
   const u32 full = rest & both;          // 17 bits
   zero_mask = ~S & 0xffu;
   return 7u * __popc(single) + 8u * __popc(two) + 12u * __popc(half) + 17u * __popc(full);
-}
-
-// predicted word from the own / previous word (v_perm) + diff constant or per-byte shifts.
-// (Specialising the usual "one unshifted class + one single-direction shift" WeightBase tables
-// behind a wave-uniform branch was A/B-tested on one box and was slower: not done.)
-template <int KIND>
-__device__ __forceinline__ u32 window_predict(u32 own, u32 prevw, u32 sel, u32 c1, u32 c2, const MpcFastModule &fm)
-{
-  const u32 b = perm(own, prevw, sel);
-  if constexpr (KIND == MPC_FK_DIFF)
-    return ((b & L7F) + c1) ^ ((b & H80) ^ c2);   // per-byte b + diff; the host split diff into c1 = low 7 bits, c2 = MSBs
-  else if constexpr (KIND == MPC_FK_WEIGHT)      // class 1 unshifted, class 2 shifted right (weights <= 1)
-    return (b & c1) | ((b >> fm.rs2) & c2);
-  else
-    return (((b << fm.ls1) >> fm.rs1) & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
 }
 
 // ---------------------------------------------------------------------------

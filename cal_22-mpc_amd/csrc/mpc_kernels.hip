@@ -1,5 +1,5 @@
 // mpc_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the per-line evaluator other
-// than the fast VPC kernel (mpc_vpc_fast.hip):
+// than the fast VPC kernel (mpc_vpc_lane.hip):
 //
 //   vpc_generic_kernel     VPC, any configuration the reference can run
 //   bdi_kernel             BDI baseline (reference src/compressor/BDI.cpp)

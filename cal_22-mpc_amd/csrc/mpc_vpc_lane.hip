@@ -1,20 +1,32 @@
-// mpc_vpc_lane.hip -- VPC multi-prediction evaluation, one LANE per line (32 / 64 byte
-// lines of fast-path configurations, see mpc_config.h: build_vpc_plan).  gfx950 / wave64.
+// mpc_vpc_lane.hip -- the hot kernel: VPC multi-prediction evaluation of lines whose
+// configuration has the plane-major scan, RootIndex 0 and "windowed" predictor tables
+// (see mpc_config.h: build_vpc_plan); 32 / 64 / 128 byte lines.  gfx950 / wave64 only.
 //
-// Mapping: lane i of a wave holds the whole line (line0 + i) in W = L/4 registers,
-// fetched with L/16 global_load_dwordx4 (the four loads of a wave cover one contiguous
-// 64*L byte span, so every fetched cache line is fully used).  Nothing crosses lanes:
-// the per-line predicates are per-lane booleans, a __ballot of one gives the
-// wave-uniform decisions (skip the prediction modules of an all-zero wave, skip a
+// Mapping: one LANE per line.  Lane i of a wave holds the whole line (line0 + i) in
+// W = L/4 registers, fetched with L/16 global_load_dwordx4 (the loads of a wave cover one
+// contiguous 64*L byte span, so every fetched cache line is fully used).  Nothing
+// crosses lanes: the per-line predicates are per-lane booleans, a __ballot of one gives
+// the wave-uniform decisions (skip the prediction modules of an all-zero wave, skip a
 // module that cannot win anywhere in the wave, skip the encoder when every line is
-// certified incompressible).  Against the 4-lanes-per-line kernel (mpc_vpc_fast.hip)
-// the byte work per line is the same SWAR arithmetic, but everything that is per
-// line -- masks, selector, winner bookkeeping, statistics, loop control -- is issued
-// once per 64 lines instead of once per 16, and the kernel is issue-bound.
+// certified incompressible).  An earlier kernel of this round held a line in L/16 lanes;
+// the byte work per line was the same SWAR arithmetic, but everything that is per line --
+// masks, selector, winner bookkeeping, statistics, loop control -- was issued once per 16
+// lines instead of once per 64, and the kernel is issue-bound.
 //
-// Stages against the reference (src/compressor/...): see the header of
-// mpc_vpc_fast.hip; the arithmetic identities (XOR stage on bytes, selector on raw
-// residues, row-0 prefilter, incompressibility certificate) are the same.
+// What the stages compute, against the reference (src/compressor/...):
+//   AllZero / AllWordSame      VPCmodules/AllZeroModule.cpp:7-15, AllWordSameModule.cpp:7-21
+//   predictors                 VPCmodules/PredictorModule.cpp:37-173
+//   residue (root first)       VPCmodules/ResidueModule.cpp:12-41
+//   bit-plane + XOR            BitplaneModule.cpp:7-51, XORModule.cpp:5-23; on bytes:
+//                              g = b ^ (b >> 1) (consecutive) or b ^ (msb ? 0x7f : 0), column 0 untouched
+//   selector (leading zero rows, ties -> later module)   VPC.cpp:366-395
+//   common encoder             VPCmodules/FPCModule.cpp:19-85 (sizes FPCModule.h:55)
+//   decision + id bits         VPC.cpp:397-407
+//   residue statistics         VPC.cpp:417-443, ResidueModule.cpp:43-74
+//
+// The kernel is a template over the sequence of predictor forms so that the module
+// sequence is unrolled; configurations whose sequence has no instantiation run the
+// same stages with a run-time loop over the modules.
 #include "mpc_kernel_common.h"
 
 #ifndef MPC_ABLATE
@@ -249,6 +261,38 @@ __device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &
   }
 }
 
+// run-time module sequence (configurations whose sequence has no instantiation): every module
+// in order, no prefilter; the selector starts from z = 0 (VPC.cpp:377-395)
+template <int W>
+__device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcParams &P, LaneBest<W> &best)
+{
+  best.z = 0;
+  best.q = -1;
+  best.root_r = 0;
+  best.cx = 0;
+#pragma unroll
+  for (int e = 0; e < W; e++) best.r[e] = 0;
+  for (int q = 0; q < P.n_pred; q++) {
+    const MpcFastModule fm = P.fm[q];
+    u32 r[W], root_r;
+    switch (fm.kind) {
+    case MPC_FK_ONEBASE: lane_residue<W, MPC_FK_ONEBASE>(c, fm, P.tab, r, root_r); break;
+    case MPC_FK_CONSEC: lane_residue<W, MPC_FK_CONSEC>(c, fm, P.tab, r, root_r); break;
+    case MPC_FK_DIFF: lane_residue<W, MPC_FK_DIFF>(c, fm, P.tab, r, root_r); break;
+    case MPC_FK_WEIGHT: lane_residue<W, MPC_FK_WEIGHT>(c, fm, P.tab, r, root_r); break;
+    default: lane_residue<W, MPC_FK_WEIGHT2>(c, fm, P.tab, r, root_r); break;
+    }
+    const u32 z = lane_leading_zero_rows<W>(r);
+    const bool take = best.z <= z;     // ties go to the later module (VPC.cpp:389)
+    best.z = take ? z : best.z;
+    best.q = take ? q : best.q;
+    best.root_r = take ? root_r : best.root_r;
+    best.cx = take ? (u32)fm.cx : best.cx;
+#pragma unroll
+    for (int e = 0; e < W; e++) best.r[e] = take ? r[e] : best.r[e];
+  }
+}
+
 // byte j of the result = OR of the four bytes of X[j] (NG == 4), or bytes 0 / 2 for X[0] / X[1] (NG == 2)
 template <int NG>
 __device__ __forceinline__ u32 fold_pack(const u32 (&X)[NG])
@@ -424,9 +468,17 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
     c.b0 = c.x[0] & 0xffu;
     c.rootb = perm(c.x[0], c.x[0], 0u);
     LaneBest<W> best;
-    const u32 keep_bits = lane_prefilters<W, NPT, 0, KINDS...>(c, P, need_mask);
-    if (keep_bits == 0) lane_last<W, NPT, 0, KINDS...>(c, P, best);
-    else lane_seq<W, NPT, 0, KINDS...>(c, P, keep_bits, best, false);
+    if constexpr (NPT > 0) {
+      const u32 keep_bits = lane_prefilters<W, NPT, 0, KINDS...>(c, P, need_mask);
+      if (keep_bits == 0) lane_last<W, NPT, 0, KINDS...>(c, P, best);
+      else lane_seq<W, NPT, 0, KINDS...>(c, P, keep_bits, best, false);
+    } else {
+      lane_seq_runtime<W>(c, P, best);
+    }
+    // without any prediction module the empty scanned array encodes to 0 bits and the line is
+    // reported uncompressed at that size (VPC.cpp:397-407 with an empty maxScanned)
+    const bool no_pred = NPT == 0 && P.n_pred == 0;
+    const u32 unc_size = (no_pred ? 0u : uncomp) + E.enc_unc;
 
     // XOR stage of the winner, on bytes: b ^ (b >> 1), or b ^ 0x7f where the MSB is set;
     // column 0 untouched.  The flavour is usually the same for the whole wave.
@@ -450,7 +502,7 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
     else open = need && (t[0] == 12345u);
     u32 enc = uncomp;
     if (__ballot(open)) enc = lane_encode<W>(t);
-    const bool keep = open && enc < uncomp;             // VPC.cpp:397-407
+    const bool keep = open && enc < uncomp && !no_pred;             // VPC.cpp:397-407
     const u64 keep_mask = __ballot(keep);
 
     // residue statistics over all positions: the winner's residues (the root position
@@ -461,7 +513,6 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
       // one wave-uniform key, sums of the raw bytes
       if constexpr (MPC_ABLATE & 4) { sum_r = c.x[3]; sum_r2 = c.x[5]; }
       else byte_sums<W>(c.x, sum_r, sum_r2);
-      const u32 unc_size = uncomp + E.enc_unc;
       if (valid) lane_run_add(rs, unc_size, sum_r, sum_r2, E);       // cluster -1: key = size
       if constexpr (OUT) {
         if (valid) {
@@ -481,7 +532,7 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
     sum_r2 = need ? sum_r2 : 0u;
     if (need) {
       chosen = keep ? P.start + best.q : -1;
-      size = keep ? enc + (u32)P.enc_bits[chosen + 1] : uncomp + E.enc_unc;
+      size = keep ? enc + (u32)P.enc_bits[chosen + 1] : unc_size;
     }
   }
 
@@ -579,8 +630,8 @@ template <int... KINDS>
 bool lane_seq_matches(const MpcVpcParams *P)
 {
   constexpr int n = sizeof...(KINDS);
-  const int kinds[n] = {KINDS...};
-  if (P->n_pred != n) return false;
+  const int kinds[n > 0 ? n : 1] = {KINDS...};
+  if (P->n_pred != n || n == 0) return false;
   for (int q = 0; q < n; q++) {
     // a periodic-table instantiation (LK_PW) needs the flag; the plain one runs any table
     const MpcFastModule &f = P->fm[q];
@@ -619,10 +670,9 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
 
 }  // namespace
 
-// 1 when the lane-per-line kernel covers the configuration (else mpc_vpc_fast.hip runs it)
-extern "C" int mpc_vpc_lane_supported(const MpcVpcParams *P)
+// 1 when the module sequence has an unrolled instantiation (else the run-time loop runs it)
+extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P)
 {
-  if (P->L != 32 && P->L != 64 && P->L != 128) return 0;
 #define X(...) if (lane_seq_matches<__VA_ARGS__>(P)) return 1;
   MPC_LANE_SEQUENCES(X)
 #undef X
@@ -660,6 +710,7 @@ extern "C" hipError_t mpc_launch_vpc_lane(const void *d_lines, u64 n_lines, cons
     }
     MPC_LANE_SEQUENCES(X)
 #undef X
+    if (!launched) e = lane_launch<>(l, (u32)take, done, P, d_sizes, d_sel, d_stats, grid, smem, stream);   // run-time sequence
     if (e != hipSuccess) return e;
   }
   return hipSuccess;

@@ -41,9 +41,7 @@ extern "C" {
 typedef struct mpc_handle mpc_handle;
 
 /* Which kernel a VPC configuration maps to (mpc_info.kernel_path). */
-#define MPC_PATH_VPC_FAST     1  /* plane-major scan, root 0, windowed tables; L/16 lanes per line */
-#define MPC_PATH_VPC_LANE     4  /* the same class of configurations, one lane per line (32 / 64
-                                    byte lines, the module sequences the kernel is built for) */
+#define MPC_PATH_VPC_FAST     1  /* plane-major scan, root 0, windowed tables: vpc_lane_kernel */
 #define MPC_PATH_VPC_GENERIC  2  /* any table / root / scan order              */
 #define MPC_PATH_BDI          3
 

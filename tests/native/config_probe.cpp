@@ -16,8 +16,8 @@ int main(int argc, char **argv)
     if (rc == 0) {
       mpc::VpcPlan plan;
       mpc::build_vpc_plan(cfg, plan);
-      printf("%s: rc 0 L %d M %d path %s tab %zu gtab %zu cert %d\n", argv[i], cfg.L, cfg.M, plan.fast ? "fast" : "generic",
-             plan.tab.size(), plan.gtab.size(), plan.params.cert_min17);
+      printf("%s: rc 0 L %d M %d path %s tab %zu gtab %zu\n", argv[i], cfg.L, cfg.M, plan.fast ? "fast" : "generic",
+             plan.tab.size(), plan.gtab.size());
     } else {
       printf("%s: rc %d %s\n", argv[i], rc, err.c_str());
     }

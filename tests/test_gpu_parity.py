@@ -39,12 +39,8 @@ def _check_vpc(mpc, oracle, cfg, lines, expect_path=None):
     return s, sel
 
 
-@pytest.mark.parametrize("L,kernel", [(32, "lane"), (64, "lane"), (128, "lane"), (32, "quad"), (64, "quad"), (128, "quad")])
-def test_vpc_fast_path_probe_config(mpc, oracle, configs, traces, monkeypatch, L, kernel):
-    """Both fast kernels on the probe configuration: one lane per line, and L/16 lanes
-    per line (MPC_VPC_KERNEL=quad makes a handle take it where the lane kernel would run)."""
-    if kernel == "quad":
-        monkeypatch.setenv("MPC_VPC_KERNEL", "quad")
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_vpc_fast_path_probe_config(mpc, oracle, configs, traces, L):
     cfg = configs.probe_config(L)
     lines = np.concatenate([
         traces.zeros(70, L), traces.word_same(70, L), traces.random_u32(2000, L),
@@ -54,13 +50,12 @@ def test_vpc_fast_path_probe_config(mpc, oracle, configs, traces, monkeypatch, L
     ])
     rng = np.random.default_rng(5)
     lines = lines[rng.permutation(len(lines))]
-    _check_vpc(mpc, oracle, cfg, lines,
-               expect_path=mpc.MPC_PATH_VPC_LANE if kernel == "lane" else mpc.MPC_PATH_VPC_FAST)
+    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
 
 
 @pytest.mark.parametrize("L", [32, 64, 128])
 def test_vpc_lane_kernel_sequences(mpc, oracle, configs, traces, L):
-    """Every module sequence the lane-per-line kernel is instantiated for, with tables
+    """Every module sequence the lane-per-line kernel is unrolled for, with tables
     that need the byte gather (base bytes not simply the previous word) and tables that
     do not, consecutive and plane-0 XOR, with and without AllWordSame."""
     lines = np.concatenate([traces.structured(5000, L, seed=21), traces.mixed(1500, L), traces.random_u32(700, L),
@@ -87,7 +82,7 @@ def test_vpc_lane_kernel_sequences(mpc, oracle, configs, traces, L):
         [az, aws, configs.weight_base(L, prev_word, w4, 0, False)],
     ]
     for mods in seqs:
-        _check_vpc(mpc, oracle, configs.make_config(L, mods), lines, expect_path=mpc.MPC_PATH_VPC_LANE)
+        _check_vpc(mpc, oracle, configs.make_config(L, mods), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
 
 
 def test_vpc_known_answers_on_gpu(mpc, configs, traces):
@@ -117,7 +112,7 @@ def test_vpc_fast_path_variants(mpc, oracle, configs, traces):
                                   configs.one_base(L, 0, False),
                                   configs.consecutive_base(L, 0, False)],
                               encoding_bits=[1, 2, 5, 7])
-    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_LANE)
+    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
     # windowed tables: previous byte / previous half-word / in-word bases, diffs incl. negatives
     base1 = [max(i - 1, 0) for i in range(L)]
     base2 = [max(i - 2, 0) for i in range(L)]
@@ -137,7 +132,7 @@ def test_vpc_fast_path_variants(mpc, oracle, configs, traces):
     _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
     # a single prediction module, and none at all
     cfg = configs.make_config(L, [{"name": "AllZero"}, {"name": "AllWordSame"}, configs.consecutive_base(L)])
-    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_LANE)
+    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
     cfg = configs.make_config(L, [{"name": "AllZero"}])
     _check_vpc(mpc, oracle, cfg, lines)
 
@@ -175,7 +170,7 @@ def test_generic_and_fast_agree(mpc, configs, traces):
     lines = np.concatenate([traces.structured(3000, L, seed=11), traces.sine_f32(1000, L)])
     cfg = configs.probe_config(L)
     fast = mpc.VPC(cfg)
-    assert fast.kernel_path == mpc.MPC_PATH_VPC_LANE
+    assert fast.kernel_path == mpc.MPC_PATH_VPC_FAST
     s1, c1 = fast.compress_lines(lines)
     eq = configs.make_config(L, [{"name": "AllZero"}, {"name": "AllWordSame"},
                                  configs.diff_base(L, [0] * L, [0] * L, 0, True),

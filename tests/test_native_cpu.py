@@ -97,7 +97,6 @@ def test_config_reader_under_sanitizers(tmp_path, configs):
     out = r.stdout.strip().split("\n")
     assert len(out) == len(files)
     assert all(": rc 0 " in line and "path fast" in line for line in out[:3])
-    assert "cert 30" in out[1]                       # 30 certain 17-bit rows at L = 64 (17*30+7 >= 512)
     assert sum(": rc -" in line for line in out[3:]) > 60
 
 

@@ -12,7 +12,7 @@ V=${VARIANTS:-0 1 2 4 8 15}
 if [ "$1" == "build" ]; then
   rm -f tools/ablate/*.so
   for a in $V; do
-    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -D${FLAG:-MPC_ABLATE}=$a -shared -o tools/ablate/libmpc_hip_$a.so $C/mpc_vpc_fast.hip $C/mpc_kernels.hip $C/mpc_capi.hip &
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -D${FLAG:-MPC_ABLATE}=$a -shared -o tools/ablate/libmpc_hip_$a.so $C/mpc_vpc_lane.hip $C/mpc_kernels.hip $C/mpc_capi.hip &
   done
   wait
 else
