@@ -77,6 +77,8 @@ public:
     (void)maxLines;
     return 0;
   }
+  // ADDITIVE.  true when GetBatch() is implemented (an exhausted or empty trace then simply yields 0)
+  virtual bool SupportsBatch() { return false; }
   // ADDITIVE.  Path of a file the evaluator may stream itself (mpc_compress_npy),
   // or "" if the loader has to be read through GetBatch()/GetCacheline().
   virtual std::string GetStreamablePath() { return ""; }

@@ -25,6 +25,7 @@ public:
   virtual void Reset();
 
   virtual unsigned long long GetBatch(uint8_t *dst, unsigned long long maxLines);
+  virtual bool SupportsBatch() { return true; }
   virtual std::string GetStreamablePath();
 
 private:

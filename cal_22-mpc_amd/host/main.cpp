@@ -2,9 +2,10 @@
 // flag-for-flag:  compressor -a ALGO -i TRACE [-c CONFIG.json] [-o OUTDIR] [-h]
 // stdout "comp.ratio: <double>", CSV rows appended to OUTDIR/<stem>_results.csv and
 // OUTDIR/<stem>_results_detail.csv.  This build evaluates VPC and BDI (the hot path
-// of SURVEY.md section 8) on the MI355X; traces are .npy files.  The other
-// algorithm names and trace formats of the reference are recognised and
-// reported as not part of this build.
+// of SURVEY.md section 8) on the MI355X; traces are .npy files or GPGPU-Sim .log
+// files (GLOBAL_ACC_R / GLOBAL_ACC_W requests, reference main.cpp:222-224).  The other
+// algorithm names and the APSim .txt format are recognised and reported as not part
+// of this build.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,6 +14,7 @@
 #include <vector>
 
 #include "BDI.h"
+#include "LoaderGPGPU.h"
 #include "LoaderNPY.h"
 #include "VPC.h"
 #include "utils.h"
@@ -89,9 +91,10 @@ int main(int argc, char **argv)
   trace::Loader *loader = nullptr;
   if (mpctext::ends_with(tracePath, ".npy")) {
     loader = new trace::LoaderNPY(tracePath);
-  } else if (mpctext::ends_with(tracePath, ".log") || mpctext::ends_with(tracePath, ".txt")) {
-    std::cout << "GPGPU-Sim .log and APSim .txt traces are not part of this build (see DESIGN.md, \"Out of scope\")."
-              << std::endl;
+  } else if (mpctext::ends_with(tracePath, ".log")) {
+    loader = new trace::gpgpusim::LoaderGPGPU(tracePath);
+  } else if (mpctext::ends_with(tracePath, ".txt")) {
+    std::cout << "APSim .txt traces are not part of this build (see DESIGN.md, \"Out of scope\")." << std::endl;
     return 1;
   } else {
     std::cerr << "Unsupported extension." << std::endl;
@@ -164,14 +167,13 @@ static comp::CompResult *compressLines(comp::Compressor *compressor, trace::Load
   const unsigned L = loader->GetCachelineSize();
   const unsigned long long cap = (64ull << 20) / L;
   std::vector<uint8_t> buf((size_t)(cap * L));
-  bool batched = false;
-  for (;;) {
-    unsigned long long n = loader->GetBatch(buf.data(), cap);
-    if (n == 0) break;
-    batched = true;
-    compressor->CompressBatch(buf.data(), n);
-  }
-  if (!batched) {
+  if (loader->SupportsBatch()) {
+    for (;;) {
+      unsigned long long n = loader->GetBatch(buf.data(), cap);
+      if (n == 0) break;
+      compressor->CompressBatch(buf.data(), n);
+    }
+  } else {
     trace::MemReq_t *memReq = new trace::MemReq_t;
     memReq->Reset();
     while (1) {

@@ -249,3 +249,46 @@ def structured(n_lines: int, line_size: int = 64, seed: int = 4242) -> np.ndarra
             w = rng.integers(0, 1 << int(rng.integers(1, 33)), W, dtype=np.uint64).astype("<u4")
             out[i] = w.view(np.uint8)
     return out
+
+
+# ---- GPGPU-Sim ".log" traces (reference src/loader/LoaderGPGPU.cpp:26-47, 93-119) -------------
+GPGPUSIM_KEYS = [("kid", 1), ("mftype", 1), ("cycle", 8), ("tpc", 4), ("sid", 4), ("wid", 4), ("pc", 4),
+                 ("instct", 4), ("addr", 8), ("reqtyp", 4), ("row", 4), ("chip", 4), ("bank", 4), ("col", 4),
+                 ("reqsiz", 4), ("data", 0), ("pad", 0)]
+GLOBAL_ACC_R, LOCAL_ACC_R, CONST_ACC_R, TEXTURE_ACC_R, GLOBAL_ACC_W, LOCAL_ACC_W, L1_WRBK_ACC, L2_WRBK_ACC, INST_ACC_R = range(9)
+
+
+def write_gpgpusim_log(path: str, lines: np.ndarray, req_types=None, seed: int = 3, tail: bytes = b"") -> str:
+    """Synthetic GPGPU-Sim memory-request trace in the layout the reference's loader
+    reads: 1 byte key count (17), 17 x (6-byte key name, 1-byte size), then per
+    request a 62-byte little-endian header (kid u8, mf_type u8, cycle u64, tpc, sid,
+    wid, pc, inst_cnt u32, mem_addr u64, req_type, row, chip, bank, col, req_size u32)
+    followed by req_size data bytes.  ``req_types[i]`` is the request type of line i
+    (default: all GLOBAL_ACC_R); ``tail`` is appended verbatim (e.g. an incomplete
+    record)."""
+    lines = np.ascontiguousarray(lines, dtype=np.uint8)
+    n, L = lines.shape
+    rng = np.random.default_rng(seed)
+    if req_types is None:
+        req_types = np.zeros(n, dtype=np.uint32)
+    req_types = np.asarray(req_types, dtype=np.uint32)
+    rec = np.zeros((n, 62 + L), dtype=np.uint8)
+    rec[:, 0] = rng.integers(0, 4, n)
+    rec[:, 1] = np.where(req_types == GLOBAL_ACC_W, 1, 0)
+    rec[:, 2:10] = np.cumsum(rng.integers(1, 50, n)).astype("<u8").view(np.uint8).reshape(n, 8)
+    for off in (10, 14, 18, 22, 26):
+        rec[:, off:off + 4] = rng.integers(0, 1 << 16, n).astype("<u4").view(np.uint8).reshape(n, 4)
+    rec[:, 30:38] = (0x7f0000000000 + rng.integers(0, 1 << 30, n).astype(np.uint64) * L).astype("<u8").view(np.uint8).reshape(n, 8)
+    rec[:, 38:42] = req_types.astype("<u4").view(np.uint8).reshape(n, 4)
+    for off in (42, 46, 50, 54):
+        rec[:, off:off + 4] = rng.integers(0, 1 << 10, n).astype("<u4").view(np.uint8).reshape(n, 4)
+    rec[:, 58:62] = np.full(n, L, dtype="<u4").view(np.uint8).reshape(n, 4)
+    rec[:, 62:] = lines
+    with open(path, "wb") as f:
+        f.write(bytes([len(GPGPUSIM_KEYS)]))
+        for name, size in GPGPUSIM_KEYS:
+            f.write(name.encode().ljust(6, b"\0")[:6] + bytes([size]))
+        f.write(rec.tobytes())
+        f.write(tail)
+    return path
+

@@ -1,12 +1,14 @@
-// loader_probe.cpp -- test driver for the host-side mirror of trace::LoaderNPY (CPU only).
-// Prints what the per-line interface (GetCacheline, as the reference driver uses it,
-// src/main.cpp:237-243) and the additive batch interface (GetBatch) deliver.
-//   loader_probe FILE.npy line|batch [batch_lines]
+// loader_probe.cpp -- test driver for the host-side mirrors of trace::LoaderNPY and
+// trace::gpgpusim::LoaderGPGPU (CPU only).  Prints what the per-line interface
+// (GetCacheline, as the reference driver uses it, src/main.cpp:208-248, including its
+// request-type filter for .log traces) and the additive batch interface (GetBatch) deliver.
+//   loader_probe FILE.npy|FILE.log line|batch [batch_lines]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
+#include "LoaderGPGPU.h"
 #include "LoaderNPY.h"
 
 static unsigned long long fnv(const uint8_t *p, size_t n, unsigned long long h)
@@ -19,16 +21,22 @@ int main(int argc, char **argv)
 {
   if (argc < 3) return 2;
   const std::string path = argv[1];
-  trace::LoaderNPY loader(path);
+  const bool is_log = path.size() > 4 && path.compare(path.size() - 4, 4, ".log") == 0;
+  trace::Loader *lp = is_log ? static_cast<trace::Loader *>(new trace::gpgpusim::LoaderGPGPU(path))
+                             : static_cast<trace::Loader *>(new trace::LoaderNPY(path));
+  trace::Loader &loader = *lp;
   const unsigned L = loader.GetCachelineSize();
   printf("lines %llu line_size %u\n", loader.GetNumLines(), L);
   unsigned long long h = 1469598103934665603ull, n = 0;
   if (!strcmp(argv[2], "line")) {
-    trace::MemReq_t *req = new trace::MemReq_t;
+    trace::MemReq_t *req = is_log ? new trace::gpgpusim::MemReqGPU_t : new trace::MemReq_t;
     req->Reset();
     while (1) {
       req = loader.GetCacheline(req);
       if (req->isEnd) break;                 // the reference tests isEnd BEFORE compressing
+      if (is_log && !trace::gpgpusim::LoaderGPGPU::isEvaluated(
+                        (uint32_t) static_cast<trace::gpgpusim::MemReqGPU_t *>(req)->reqType))
+        continue;                            // main.cpp:222-224
       if (req->data.size() != L || req->reqSize != L) return 3;
       h = fnv(req->data.data(), L, h);
       n++;
@@ -45,5 +53,6 @@ int main(int argc, char **argv)
     }
   }
   printf("delivered %llu hash %llu\n", n, h);
+  delete lp;
   return 0;
 }

@@ -63,8 +63,10 @@ def test_out_of_scope_algorithms_and_formats(cli, traces, tmp_path):
     for algo in ("FPC", "BPC", "CPACK", "SC2", "PATTERN", "VIEWER"):
         r = run([cli, "-a", algo, "-i", p, "-o", str(tmp_path)])
         assert r.returncode == 1 and "not part of this build" in r.stdout
-    r = run([cli, "-a", "BDI", "-i", str(d / "t.log"), "-o", str(tmp_path)])
+    r = run([cli, "-a", "BDI", "-i", str(d / "t.txt"), "-o", str(tmp_path)])
     assert r.returncode == 1 and "not part of this build" in r.stdout
+    r = run([cli, "-a", "BDI", "-i", str(d / "missing.log"), "-o", str(tmp_path)])
+    assert r.returncode == 1 and "Failed to open a file" in r.stdout
     r = run([cli, "-a", "BDI", "-i", str(d / "t.bin"), "-o", str(tmp_path)])
     assert r.returncode != 0 and "Unsupported extension" in r.stderr
 
@@ -172,6 +174,47 @@ def test_cli_bdi(cli, oracle, traces, tmp_path):
         "".join(f"{o.st.counts[i]}," for i in range(9)) + "\n"
     assert (tmp_path / "BDI_results.csv").read_text() == hdr + row
     assert not (tmp_path / "BDI_results_detail.csv").exists()
+
+
+@pytest.mark.gpu
+def test_cli_gpgpusim_log(cli, oracle, configs, traces, tmp_path):
+    """GPGPU-Sim .log traces through the CLI: only GLOBAL_ACC_R / GLOBAL_ACC_W requests are
+    evaluated (reference main.cpp:222-224), every complete record counts (no dropped last
+    row), an incomplete trailing record is ignored.  Expected text from the oracle run on
+    oracle/gpgpusim_log.py's reading of the same file."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import gpgpusim_log as G
+    ds = tmp_path / "sim"
+    ds.mkdir()
+    lines = np.concatenate([traces.structured(3000, 64, seed=4), traces.mixed(2000, 64), traces.random_u32(500, 64),
+                            traces.zeros(100, 64)])
+    lines = lines[np.random.default_rng(2).permutation(len(lines))]
+    types = np.random.default_rng(3).integers(0, 9, len(lines))
+    one = open(traces.write_gpgpusim_log(str(tmp_path / "one.log"), lines[:1]), "rb").read()[1 + 7 * 17:]
+    p = traces.write_gpgpusim_log(str(ds / "kernel7.log"), lines, types, tail=one[:-3])
+    kept = G.evaluated_lines(p)
+    assert len(kept) == int(((types == 0) | (types == 4)).sum())
+    cfg = configs.probe_config(64)
+    cfg_path = configs.write_config(cfg, str(tmp_path / "probe64.json"))
+    r = run([cli, "-a", "VPC", "-i", p, "-c", cfg_path, "-o", str(tmp_path)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    o = oracle.VpcOracle(cfg)
+    o.compress(kept)
+    assert r.stdout.strip().split("\n")[-1] == "comp.ratio: " + fmt_double(o.st.comp_ratio)
+    row, det = vpc_expected_rows(o, "sim_kernel7")
+    h1, h2 = vpc_headers(6)
+    assert (tmp_path / "probe64_results.csv").read_text() == h1 + row + "\n"
+    assert (tmp_path / "probe64_results_detail.csv").read_text() == h2 + det + "\n"
+    r = run([cli, "-a", "BDI", "-i", p, "-o", str(tmp_path)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    ob = oracle.BdiOracle(64)
+    ob.compress(kept)
+    assert r.stdout.strip().split("\n")[-1] == "comp.ratio: " + fmt_double(ob.st.comp_ratio)
+    # a trace without any global access: nothing evaluated, CompRatio keeps its initial 0 (CompResult.h:24-27)
+    p2 = traces.write_gpgpusim_log(str(ds / "none.log"), lines[:50], np.full(50, 2))
+    r = run([cli, "-a", "BDI", "-i", p2, "-o", str(tmp_path)])
+    assert r.returncode == 0 and r.stdout.strip().split("\n")[-1] == "comp.ratio: 0"
 
 
 @pytest.mark.gpu

@@ -4,6 +4,7 @@ reader and of the oracle (sanitizers are not available on the GPU pool, so here)
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -33,7 +34,7 @@ def _fnv(data: bytes) -> int:
 def loader_probe(tmp_path_factory):
     tmp = str(tmp_path_factory.mktemp("native"))
     return _build(tmp, "loader_probe", ["g++", "-std=c++17", *SAN, "-I", HOST, os.path.join(NATIVE, "loader_probe.cpp"),
-                                        os.path.join(HOST, "LoaderNPY.cpp")])
+                                        os.path.join(HOST, "LoaderNPY.cpp"), os.path.join(HOST, "LoaderGPGPU.cpp")])
 
 
 @pytest.mark.parametrize("n,L", [(1, 64), (2, 64), (1000, 32), (777, 128)])
@@ -57,6 +58,47 @@ def test_loader_npy_rejects_bad_files(loader_probe, tmp_path):
     for name in ("f.npy", "d3.npy", "fo.npy", "junk.npy", "missing.npy"):
         r = subprocess.run([loader_probe, str(tmp_path / name), "line"], capture_output=True, text=True)
         assert r.returncode == 1 and "Invalid File!" in r.stdout, (name, r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("n,L", [(1, 64), (300, 32), (777, 128)])
+def test_loader_gpgpusim_log_matches_restatement(loader_probe, traces, tmp_path, n, L):
+    """The C++ LoaderGPGPU (per-record interface + the driver's request-type filter, and the
+    additive GetBatch) against oracle/gpgpusim_log.py on synthetic .log traces: every request
+    type, an incomplete trailing record, an incomplete trailing header."""
+    sys.path.insert(0, ROOT)
+    from oracle import gpgpusim_log as G
+    lines = traces.structured(n, L, seed=n + 1)
+    types = np.random.default_rng(n).integers(0, 9, n)
+    one = open(traces.write_gpgpusim_log(str(tmp_path / "one.log"), lines[:1]), "rb").read()[1 + 7 * 17:]
+    for k, tail in enumerate((b"", one[:-1], one[:17])):     # complete; last data byte missing; header cut off
+        p = traces.write_gpgpusim_log(str(tmp_path / f"t{k}.log"), lines, types, tail=tail)
+        kept = G.evaluated_lines(p)
+        assert (kept == lines[(types == 0) | (types == 4)]).all() and G.line_size(p) == L
+        want = _fnv(kept.tobytes())
+        for mode in (["line"], ["batch", "100"], ["batch", "1"]):
+            r = subprocess.run([loader_probe, p] + mode, capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+            out = r.stdout.strip().split("\n")
+            assert out[0] == f"lines {n} line_size {L}"           # GetNumLines counts every complete record
+            assert out[1] == f"delivered {len(kept)} hash {want}"
+
+
+def test_loader_gpgpusim_log_rejects_bad_files(loader_probe, traces, tmp_path):
+    lines = traces.structured(10, 64)
+    good = open(traces.write_gpgpusim_log(str(tmp_path / "g.log"), lines), "rb").read()
+    (tmp_path / "keys.log").write_bytes(bytes([16]) + good[1:])          # wrong key count
+    (tmp_path / "short.log").write_bytes(good[:50])                      # header cut off
+    for name in ("keys.log", "short.log"):
+        r = subprocess.run([loader_probe, str(tmp_path / name), "line"], capture_output=True, text=True)
+        assert r.returncode == 1 and "header of the GPGPU-sim trace file is not valid" in r.stdout, (name, r.stdout)
+    r = subprocess.run([loader_probe, str(tmp_path / "missing.log"), "line"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Failed to open a file" in r.stdout
+    # requests of two sizes among the evaluated types: refused by the batch interface (documented deviation)
+    a = open(traces.write_gpgpusim_log(str(tmp_path / "a.log"), lines), "rb").read()
+    b = open(traces.write_gpgpusim_log(str(tmp_path / "b.log"), traces.structured(4, 32)), "rb").read()
+    (tmp_path / "mixed.log").write_bytes(a + b[1 + 7 * 17:])
+    r = subprocess.run([loader_probe, str(tmp_path / "mixed.log"), "batch", "100"], capture_output=True, text=True)
+    assert r.returncode == 1 and "mixes request sizes" in r.stdout
 
 
 def test_config_reader_under_sanitizers(tmp_path, configs):
