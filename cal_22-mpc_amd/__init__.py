@@ -88,6 +88,8 @@ def lib() -> C.CDLL:
             "mpc_config_describe": ([C.c_char_p, C.c_char_p, C.c_size_t], C.c_int),
             "mpc_compress_npy": ([H, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)], C.c_int),
             "mpc_npy_shape": ([C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], C.c_int),
+            "mpc_compress_gpgpusim_log": ([H, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], C.c_int),
+            "mpc_gpgpusim_log_line_size": ([C.c_char_p, C.POINTER(C.c_uint32)], C.c_int),
             "mpc_synth_fill": ([C.c_void_p, C.c_uint64, C.c_uint, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p], C.c_int),
             "mpc_read_bandwidth_probe": ([C.c_void_p, C.c_uint64, C.c_void_p], C.c_int),
         }
@@ -103,8 +105,18 @@ EXPORTED_SYMBOLS = [
     "mpc_create_vpc", "mpc_create_vpc_from_string", "mpc_create_bdi", "mpc_destroy", "mpc_get_info",
     "mpc_last_error", "mpc_compress_batch", "mpc_compress_batch_device", "mpc_sync", "mpc_stats_len",
     "mpc_stats_get", "mpc_stats_merge", "mpc_stats_set", "mpc_stats_reset", "mpc_config_describe",
-    "mpc_compress_npy", "mpc_npy_shape", "mpc_synth_fill", "mpc_read_bandwidth_probe",
+    "mpc_compress_npy", "mpc_npy_shape", "mpc_compress_gpgpusim_log", "mpc_gpgpusim_log_line_size",
+    "mpc_synth_fill", "mpc_read_bandwidth_probe",
 ]
+
+
+def gpgpusim_log_line_size(path: str) -> int:
+    """Line size of a GPGPU-Sim ``.log`` trace: req_size of its first request (no device needed)."""
+    sz = C.c_uint32()
+    rc = lib().mpc_gpgpusim_log_line_size(path.encode(), C.byref(sz))
+    if rc != 0:
+        raise MpcError(rc, (lib().mpc_last_error(None) or b"").decode())
+    return int(sz.value)
 
 
 def describe_config(cfg) -> Dict:
@@ -173,6 +185,14 @@ class _Evaluator:
         self._check(lib().mpc_compress_npy(self._h, path.encode(), first_row, n_rows,
                                            1 if skip_last_row else 0, C.byref(done)))
         return int(done.value)
+
+    def compress_gpgpusim_log(self, path: str):
+        """Stream a GPGPU-Sim ``.log`` trace (reference ``LoaderGPGPU.cpp`` + the driver's
+        GLOBAL_ACC_R / GLOBAL_ACC_W filter, ``main.cpp:222-224``); returns
+        (requests read, lines evaluated)."""
+        req, done = C.c_uint64(), C.c_uint64()
+        self._check(lib().mpc_compress_gpgpusim_log(self._h, path.encode(), C.byref(req), C.byref(done)))
+        return int(req.value), int(done.value)
 
     def sync(self) -> None:
         self._check(lib().mpc_sync(self._h))

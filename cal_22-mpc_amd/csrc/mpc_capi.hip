@@ -539,6 +539,124 @@ int mpc_compress_npy(mpc_handle *h, const char *path, uint64_t first_row, uint64
   return rc;
 }
 
+namespace {
+
+constexpr int kLogKeys = 17, kLogRecordHeader = 62;
+
+// validates the file header of a GPGPU-Sim trace (LoaderGPGPU.cpp:93-119)
+int log_open(const char *path, FILE **out, std::string &err)
+{
+  FILE *f = fopen(path, "rb");
+  if (!f) { err = std::string("Failed to open a file. Check the path of the file: ") + path; return MPC_E_NOENT; }
+  unsigned char hdr[1 + 7 * kLogKeys];
+  if (fread(hdr, 1, sizeof(hdr), f) != sizeof(hdr) || hdr[0] != kLogKeys) {
+    fclose(f);
+    err = "The header of the GPGPU-sim trace file is not valid.";
+    return MPC_E_PARSE;
+  }
+  *out = f;
+  return MPC_OK;
+}
+
+// one request header; false at the end of the file (or inside an incomplete header)
+bool log_next(FILE *f, uint32_t *req_type, uint32_t *req_size)
+{
+  unsigned char h[kLogRecordHeader];
+  if (fread(h, 1, sizeof(h), f) != sizeof(h)) return false;
+  std::memcpy(req_type, h + 38, 4);
+  std::memcpy(req_size, h + 58, 4);
+  return true;
+}
+
+}  // namespace
+
+int mpc_gpgpusim_log_line_size(const char *log_path, uint32_t *line_size)
+{
+  if (!log_path || !line_size) return MPC_E_INVAL;
+  *line_size = 0;
+  FILE *f = nullptr;
+  std::string err;
+  int rc = log_open(log_path, &f, err);
+  if (rc != MPC_OK) return set_err(nullptr, rc, err);
+  uint32_t t = 0, sz = 0;
+  if (log_next(f, &t, &sz)) *line_size = sz;
+  fclose(f);
+  return MPC_OK;
+}
+
+int mpc_compress_gpgpusim_log(mpc_handle *h, const char *log_path, uint64_t *requests_read, uint64_t *lines_done)
+{
+  if (!h || !log_path) return MPC_E_INVAL;
+  if (requests_read) *requests_read = 0;
+  if (lines_done) *lines_done = 0;
+  FILE *f = nullptr;
+  std::string err;
+  int rc = log_open(log_path, &f, err);
+  if (rc != MPC_OK) return set_err(h, rc, err);
+  std::vector<char> iobuf(8u << 20);
+  setvbuf(f, iobuf.data(), _IOFBF, iobuf.size());
+  if (hipSetDevice(h->device) != hipSuccess) { fclose(f); return set_err(h, MPC_E_HIP, "hipSetDevice failed"); }
+  rc = ensure_slots(h);
+  if (rc != MPC_OK) { fclose(f); return rc; }
+  const u64 L = (u64)h->L;
+  u64 requests = 0, lines = 0, fill = 0;
+  bool first = true;
+  int which = 0;
+  rc = retire(h, h->slots[which]);
+  while (rc == MPC_OK) {
+    uint32_t req_type = 0, req_size = 0;
+    if (!log_next(f, &req_type, &req_size)) break;
+    if (first && req_size != L) {
+      rc = set_err(h, MPC_E_INVAL, "trace line size " + std::to_string(req_size) + " differs from the evaluator's " + std::to_string(L));
+      break;
+    }
+    first = false;
+    const bool evaluated = req_type == 0u || req_type == 4u;   // GLOBAL_ACC_R, GLOBAL_ACC_W
+    if (evaluated && req_size != L) {
+      rc = set_err(h, MPC_E_INVAL, "the GPGPU-sim trace mixes request sizes (" + std::to_string(req_size) + " after " + std::to_string(L) + " bytes)");
+      break;
+    }
+    Slot &s = h->slots[which];
+    if (evaluated) {
+      if (fread(s.h_in + fill * L, 1, (size_t)L, f) != (size_t)L) break;   // incomplete trailing request
+      fill++;
+    } else {
+      // skip the payload; a short file shows up as a failing read of the next header
+      if (req_size > (1u << 20)) { rc = set_err(h, MPC_E_PARSE, "unreasonable request size in the GPGPU-sim trace"); break; }
+      char skip[4096];
+      u64 left = req_size;
+      bool short_read = false;
+      while (left) {
+        const size_t take = left < sizeof(skip) ? (size_t)left : sizeof(skip);
+        if (fread(skip, 1, take, f) != take) { short_read = true; break; }
+        left -= take;
+      }
+      if (short_read) break;
+    }
+    requests++;
+    if (fill == (u64)h->stage_lines) {
+      rc = submit(h, s, fill, nullptr, nullptr);
+      if (rc != MPC_OK) break;
+      lines += fill;
+      fill = 0;
+      which ^= 1;
+      rc = retire(h, h->slots[which]);
+    }
+  }
+  if (rc == MPC_OK && fill) {
+    rc = submit(h, h->slots[which], fill, nullptr, nullptr);
+    if (rc == MPC_OK) lines += fill;
+  }
+  fclose(f);
+  int rc2 = sync_all(h);
+  if (rc == MPC_OK) rc = rc2;
+  if (rc == MPC_OK) {
+    if (requests_read) *requests_read = requests;
+    if (lines_done) *lines_done = lines;
+  }
+  return rc;
+}
+
 int mpc_stats_len(const mpc_handle *h, uint64_t *len)
 {
   if (!h || !len) return MPC_E_INVAL;

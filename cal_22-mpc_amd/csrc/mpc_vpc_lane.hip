@@ -346,6 +346,65 @@ __device__ __forceinline__ bool lane_certified(const u32 (&t)[W])
   return bound >= 32u * W;
 }
 
+// Common encoder's row classes for FOUR column groups at once (t = their 16 words): the 16
+// columns are brought into "packed" form -- P[c] holds column c of the four groups, one
+// byte per group, bit 7-p = plane p -- with 4x4 byte transposes, and every step of
+// encode_rows (mpc_kernel_common.h) then runs once on packed words instead of once per
+// group.  Returns the bits of the non-zero rows; Z = packed zero-row masks.
+__device__ __forceinline__ u32 encode_rows_x4(const u32 *t, u32 &Z)
+{
+  u32 P[16];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {     // word e of each group -> columns 4e .. 4e+3
+    const u32 lo01 = perm(t[4 + e], t[e], 0x05010400u), hi01 = perm(t[4 + e], t[e], 0x07030602u);
+    const u32 lo23 = perm(t[12 + e], t[8 + e], 0x05010400u), hi23 = perm(t[12 + e], t[8 + e], 0x07030602u);
+    P[4 * e] = perm(lo23, lo01, 0x05040100u);
+    P[4 * e + 1] = perm(lo23, lo01, 0x07060302u);
+    P[4 * e + 2] = perm(hi23, hi01, 0x05040100u);
+    P[4 * e + 3] = perm(hi23, hi01, 0x07060302u);
+  }
+  // per plane: S = bit set in >= 1 column, T = in >= 2, U = in >= 3 (carry-save tree over the columns)
+  u32 s1[8], t1[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    s1[i] = P[2 * i] | P[2 * i + 1];
+    t1[i] = P[2 * i] & P[2 * i + 1];
+  }
+  // two ones in adjacent columns c, c+1 (c = 0..14)
+  u32 A = t1[0] | t1[1] | t1[2] | t1[3] | t1[4] | t1[5] | t1[6] | t1[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) A |= P[2 * i + 1] & P[2 * i + 2];
+  const u32 Sf = s1[0] | s1[1] | s1[2] | s1[3];   // columns 0..7
+  const u32 Sb = s1[4] | s1[5] | s1[6] | s1[7];   // columns 8..15
+  const u32 S = Sf | Sb;
+  u32 s2[4], t2[4], u2[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const u32 sa = s1[2 * i], sb = s1[2 * i + 1], ta = t1[2 * i], tb = t1[2 * i + 1];
+    s2[i] = sa | sb;
+    t2[i] = ta | tb | (sa & sb);
+    u2[i] = (ta & sb) | (sa & tb);
+  }
+  u32 s3[2], t3[2], u3[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const u32 sa = s2[2 * i], sb = s2[2 * i + 1], ta = t2[2 * i], tb = t2[2 * i + 1];
+    s3[i] = sa | sb;
+    t3[i] = ta | tb | (sa & sb);
+    u3[i] = u2[2 * i] | u2[2 * i + 1] | (ta & sb) | (sa & tb);
+  }
+  const u32 T = t3[0] | t3[1] | (s3[0] & s3[1]);
+  const u32 U = u3[0] | u3[1] | (t3[0] & s3[1]) | (s3[0] & t3[1]);
+  const u32 single = S & ~T;             // exactly one 1: 7 bits
+  const u32 two = T & ~U & A;            // exactly two, adjacent: 8 bits
+  const u32 rest = S & ~single & ~two;
+  const u32 both = Sf & Sb;
+  const u32 half = rest & ~both;         // one 8-column half empty: 12 bits
+  const u32 full = rest & both;          // 17 bits
+  Z = ~S;
+  return 7u * __popc(single) + 8u * __popc(two) + 12u * __popc(half) + 17u * __popc(full);
+}
+
 // common encoder (FPCModule.cpp:19-85) over all rows of the line: non-zero rows by
 // pattern, zero rows as runs in row order (plane-major, then column group)
 template <int W>
@@ -354,11 +413,20 @@ __device__ __forceinline__ u32 lane_encode(const u32 (&t)[W])
   constexpr int NG = W / 4;
   u32 bits = 0;
   u64 ZP = 0;     // byte j of ZP: zero-row mask of column group j (bit 7-p = plane p)
+  if constexpr (NG >= 4) {
 #pragma unroll
-  for (int j = 0; j < NG; j++) {
-    u32 Z;
-    bits += encode_rows(&t[4 * j], Z);
-    ZP |= (u64)Z << (8 * j);
+    for (int h = 0; h < NG / 4; h++) {
+      u32 Z;
+      bits += encode_rows_x4(&t[16 * h], Z);
+      ZP |= (u64)Z << (32 * h);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NG; j++) {
+      u32 Z;
+      bits += encode_rows(&t[4 * j], Z);
+      ZP |= (u64)Z << (8 * j);
+    }
   }
   // previous row of (p, j): (p, j-1), or (p-1, NG-1) for j = 0; next row: (p, j+1), or (p+1, 0)
   constexpr u64 all = NG == 8 ? ~0ull : ((1ull << (8 * (NG & 7))) - 1ull);

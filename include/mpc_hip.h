@@ -126,6 +126,20 @@ int mpc_compress_npy(mpc_handle *h, const char *npy_path, uint64_t first_row,
 /* Header probe: shape of a 2-D uint8 .npy file. */
 int mpc_npy_shape(const char *npy_path, uint64_t *n_rows, uint64_t *line_size);
 
+/* ---- GPGPU-Sim ".log" traces (replaces trace::gpgpusim::LoaderGPGPU,
+ *      LoaderGPGPU.cpp:26-55, 93-119, plus the driver's filter, main.cpp:222-224)
+ * File: 1 byte key count (17), 17 x (6-byte key, 1-byte size), then requests of
+ * 62 header bytes + req_size data bytes.  Every complete request is read; only
+ * GLOBAL_ACC_R (0) and GLOBAL_ACC_W (4) requests are evaluated; an incomplete
+ * trailing request is ignored.  The line size is the req_size of the first
+ * request (GetCachelineSize, LoaderGPGPU.cpp:16-24) and must equal the handle's;
+ * an evaluated request of another size is an error (MPC_E_INVAL).
+ * requests_read / lines_done may be NULL.                                    */
+int mpc_compress_gpgpusim_log(mpc_handle *h, const char *log_path, uint64_t *requests_read,
+                              uint64_t *lines_done);
+/* Header probe: req_size of the first request (0 for a trace without requests). */
+int mpc_gpgpusim_log_line_size(const char *log_path, uint32_t *line_size);
+
 /* ---- measurement helpers (bench.py; not part of the evaluator) -----------
  * Synthetic device-resident traces of SURVEY.md 8d, generated on the GPU:
  * kind 0 zeros, 1 random u32, 2 fp32 sine, 3 mixed int/fp, 4 pointer qwords.

@@ -113,3 +113,17 @@ def test_npy_shape_probe(mpc, traces, tmp_path):
     assert (r.value, c.value) == (37, 64)
     np.save(str(tmp_path / "f.npy"), np.zeros((4, 64), dtype=np.float32))
     assert mpc.lib().mpc_npy_shape(str(tmp_path / "f.npy").encode(), C.byref(r), C.byref(c)) == -22
+
+
+def test_gpgpusim_log_probe_needs_no_device(mpc, traces, tmp_path):
+    lines = traces.structured(20, 128)
+    p = traces.write_gpgpusim_log(str(tmp_path / "t.log"), lines)
+    assert mpc.gpgpusim_log_line_size(p) == 128
+    (tmp_path / "bad.log").write_bytes(b"\x10" + bytes(200))
+    with pytest.raises(mpc.MpcError) as e:
+        mpc.gpgpusim_log_line_size(str(tmp_path / "bad.log"))
+    assert e.value.code == -74 and "header of the GPGPU-sim trace file is not valid" in str(e.value)
+    with pytest.raises(mpc.MpcError) as e:
+        mpc.gpgpusim_log_line_size(str(tmp_path / "missing.log"))
+    assert e.value.code == -2
+

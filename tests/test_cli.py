@@ -126,21 +126,27 @@ def test_bin_run_vpc_dataset(cli, oracle, configs, traces, tmp_path):
     traces.save_npy(str(ds / "splitA" / "zeros_testset.npy"), zeros)
     traces.save_npy(str(ds / "splitA" / "mix_trainset.npy"), mix)
     traces.save_npy(str(ds / "top.npy"), mix[:1001])
+    # a GPGPU-Sim .log in the split directory: its rows go to out/, not out/<split>/ (bin/run:37-53)
+    log_types = np.random.default_rng(6).integers(0, 9, 2000)
+    traces.write_gpgpusim_log(str(ds / "splitA" / "kern.log"), mix[:2000], log_types)
+    log_lines = mix[:2000][(log_types == 0) | (log_types == 4)]
     r = run([os.path.join(BIN, "run"), "VPC", str(ds), str(out), cfg_path])
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().split("\n")
     # echo lines + comp.ratio lines, in directory order
     o = oracle.VpcOracle(cfg)
     expect_stdout, sum_rows, det_rows = [], {"splitA": [], "": []}, {"splitA": [], "": []}
-    for split, name, data in (("splitA", "mix_trainset", mix), ("splitA", "zeros_testset", zeros), ("", "top", mix[:1001])):
+    for split, name, data in (("splitA", "mix_trainset", mix[:-1]), ("splitA", "zeros_testset", zeros[:-1]),
+                              ("log", "kern", log_lines), ("", "top", mix[:1000])):
         o.reset()
-        o.compress(data[:-1])                       # the driver never sees the last row
+        o.compress(data)                            # .npy: the driver never sees the last row
         # bin/run echoes "$split : name"; for top-level files $split is whatever the
         # directory walk left behind (the last entry: "top.npy"), as in the reference
         label = ("splitA : " if split else "top.npy : ") + name
         expect_stdout += [label, "comp.ratio: " + fmt_double(o.st.comp_ratio)]
         parent = "splitA" if split else "data"
         row, det = vpc_expected_rows(o, f"{parent}_{name}")
+        split = "" if split == "log" else split
         sum_rows[split].append(row)
         det_rows[split].append(det)
         if name == "zeros_testset":
@@ -154,7 +160,7 @@ def test_bin_run_vpc_dataset(cli, oracle, configs, traces, tmp_path):
     # a second run appends rows without repeating the header
     r = run([os.path.join(BIN, "run"), "VPC", str(ds), str(out), cfg_path])
     assert r.returncode == 0
-    assert (out / "probe64_results.csv").read_text() == h1 + (sum_rows[""][0] + "\n") * 2
+    assert (out / "probe64_results.csv").read_text() == h1 + "".join(r_ + "\n" for r_ in sum_rows[""]) * 2
 
 
 @pytest.mark.gpu

@@ -260,6 +260,51 @@ def test_stager_multi_chunk_and_npy(mpc, oracle, configs, traces, tmp_path):
     assert (ev.stats_vector() == o.stats_vector()).all()
 
 
+def test_gpgpusim_log_streaming(mpc, oracle, configs, traces, tmp_path):
+    """mpc_compress_gpgpusim_log: several staging chunks, every request type, an incomplete
+    trailing request; against the oracle on oracle/gpgpusim_log.py's reading of the file."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    from oracle import gpgpusim_log as G
+    L = 128
+    n = 1_600_000                          # > two 64 MiB staging chunks of evaluated lines
+    lines = traces.structured(n, L, seed=77)
+    types = np.random.default_rng(5).choice([0, 4, 0, 4, 0, 4, 0, 1, 2, 8], n)
+    one = open(traces.write_gpgpusim_log(str(tmp_path / "one.log"), lines[:1]), "rb").read()[1 + 7 * 17:]
+    p = traces.write_gpgpusim_log(str(tmp_path / "big.log"), lines, types, tail=one[:-1])
+    kept = lines[(types == 0) | (types == 4)]
+    assert len(kept) > 2 * ((64 << 20) // L)
+    assert mpc.gpgpusim_log_line_size(p) == L
+    assert (G.evaluated_lines(p) == kept).all()
+    # BDI against the oracle on everything; VPC against the (oracle-checked) host-buffer path on
+    # everything and against the oracle on a prefix
+    ev, o = mpc.BDI(L), oracle.BdiOracle(L)
+    assert ev.compress_gpgpusim_log(p) == (n, len(kept))
+    o.compress(kept)
+    assert (ev.stats_vector() == o.stats_vector()).all()
+    ev.close()
+    cfg = configs.probe_config(L)
+    ev, ev2 = mpc.VPC(cfg), mpc.VPC(cfg)
+    assert ev.compress_gpgpusim_log(p) == (n, len(kept))
+    ev2.compress_lines(kept)
+    assert (ev.stats_vector() == ev2.stats_vector()).all()
+    ev.close()
+    ev2.close()
+    small = traces.write_gpgpusim_log(str(tmp_path / "small.log"), lines[:30000], types[:30000])
+    ev, o = mpc.VPC(cfg), oracle.VpcOracle(cfg)
+    ev.compress_gpgpusim_log(small)
+    o.compress(G.evaluated_lines(small))
+    assert (ev.stats_vector() == o.stats_vector()).all()
+    ev.close()
+    # wrong line size / mixed sizes are errors, not crashes
+    ev = mpc.BDI(64)
+    with pytest.raises(mpc.MpcError) as e:
+        ev.compress_gpgpusim_log(p)
+    assert e.value.code == -22
+    ev.close()
+
+
 def test_device_resident_path_and_synth(mpc, oracle, configs, traces):
     import torch
     dev = torch.device("cuda:0")
