@@ -212,3 +212,13 @@ def test_only_allzero_config(oracle, configs, traces):
     v = oracle.VpcOracle(cfg)
     s, sel = v.compress(traces.random_u32(4))
     assert (s == 1).all() and (sel == -1).all()
+
+
+def test_bdi_screen_stress_trace_reaches_every_outcome(oracle, traces):
+    """The trace that drives the BDI kernel's screening thresholds on the GPU must keep
+    exercising every (base, delta) selection and the uncompressed outcome."""
+    for L in (32, 64, 128):
+        o = oracle.BdiOracle(L)
+        _, sel = o.compress(traces.bdi_screen_stress(4800, L))
+        assert set(np.unique(sel)) >= {2, 3, 4, 5, 6, 7, 8}, (L, np.unique(sel))
+
