@@ -137,6 +137,51 @@ def test_vpc_fast_path_variants(mpc, oracle, configs, traces):
     _check_vpc(mpc, oracle, cfg, lines)
 
 
+def _random_windowed_config(configs, rng, L):
+    """Random fast-path configuration: 1..6 prediction modules of random kinds; windowed base
+    tables (base byte in the own or the previous 32-bit word, never ahead of the byte), random
+    diffs, weights with at most two shift distances, random XOR flavour, optional AllWordSame,
+    random id bits."""
+    def windowed_base():
+        b = [0] * L
+        for i in range(1, L):
+            lo = max(4 * (i // 4) - 4, 0)
+            b[i] = int(rng.integers(lo, 4 * (i // 4) + 4))
+        return b
+    mods = [{"name": "AllZero"}]
+    if rng.integers(0, 2):
+        mods.append({"name": "AllWordSame"})
+    for _ in range(int(rng.integers(1, 7))):
+        kind = int(rng.integers(0, 4))
+        cx = bool(rng.integers(0, 2))
+        if kind == 0:
+            mods.append(configs.one_base(L, 0, cx))
+        elif kind == 1:
+            mods.append(configs.consecutive_base(L, 0, cx))
+        elif kind == 2:
+            diff = [int(x) for x in rng.integers(-128, 128, L)] if rng.integers(0, 2) else [int(rng.integers(-3, 4))] * L
+            mods.append(configs.diff_base(L, windowed_base(), diff, 0, cx))
+        else:
+            pool = [[1.0, 0.5], [1.0, 0.25], [2.0, 1.0], [2.0, 0.5], [1.0, 1.0], [0.125, 4.0], [1.0, 300.0]][int(rng.integers(0, 7))]
+            w = [pool[int(rng.integers(0, 2))] for _ in range(L)]
+            mods.append(configs.weight_base(L, windowed_base(), w, 0, cx))
+    enc = [int(x) for x in rng.integers(0, 9, len(mods) + 1)] if rng.integers(0, 2) else None
+    return configs.make_config(L, mods, enc)
+
+
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_vpc_fast_path_random_configs(mpc, oracle, configs, traces, L):
+    """Randomly drawn fast-path configurations (mostly run-time module sequences) on a mixed
+    trace, bit-exact against the oracle."""
+    rng = np.random.default_rng(1000 + L)
+    lines = np.concatenate([traces.structured(2500, L, seed=L), traces.mixed(800, L), traces.random_u32(300, L),
+                            traces.sine_f32(512, L), traces.zeros(20, L), traces.word_same(20, L)])
+    lines = lines[rng.permutation(len(lines))]
+    for _ in range(10):
+        cfg = _random_windowed_config(configs, rng, L)
+        _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+
+
 @pytest.mark.parametrize("L", [32, 64, 128, 48])
 def test_vpc_generic_path(mpc, oracle, configs, traces, L):
     rng = np.random.default_rng(L)
