@@ -85,6 +85,9 @@ def lib() -> C.CDLL:
             "mpc_stats_merge": ([H, C.c_void_p, C.c_size_t], C.c_int),
             "mpc_stats_set": ([H, C.c_void_p, C.c_size_t], C.c_int),
             "mpc_stats_reset": ([H], C.c_int),
+            "mpc_stats_raw_len": ([H, C.POINTER(C.c_uint64)], C.c_int),
+            "mpc_stats_copy_raw_device": ([H, C.c_void_p, C.c_void_p], C.c_int),
+            "mpc_stats_from_raw": ([H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t], C.c_int),
             "mpc_config_describe": ([C.c_char_p, C.c_char_p, C.c_size_t], C.c_int),
             "mpc_compress_npy": ([H, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)], C.c_int),
             "mpc_npy_shape": ([C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], C.c_int),
@@ -104,7 +107,8 @@ def lib() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "mpc_create_vpc", "mpc_create_vpc_from_string", "mpc_create_bdi", "mpc_destroy", "mpc_get_info",
     "mpc_last_error", "mpc_compress_batch", "mpc_compress_batch_device", "mpc_sync", "mpc_stats_len",
-    "mpc_stats_get", "mpc_stats_merge", "mpc_stats_set", "mpc_stats_reset", "mpc_config_describe",
+    "mpc_stats_get", "mpc_stats_merge", "mpc_stats_set", "mpc_stats_reset", "mpc_stats_raw_len",
+    "mpc_stats_copy_raw_device", "mpc_stats_from_raw", "mpc_config_describe",
     "mpc_compress_npy", "mpc_npy_shape", "mpc_compress_gpgpusim_log", "mpc_gpgpusim_log_line_size",
     "mpc_synth_fill", "mpc_read_bandwidth_probe",
 ]
@@ -201,6 +205,23 @@ class _Evaluator:
     def stats_vector(self) -> np.ndarray:
         v = np.zeros(self.stats_len, dtype=np.uint64)
         self._check(lib().mpc_stats_get(self._h, v.ctypes.data, self.stats_len))
+        return v
+
+    def stats_raw_len(self) -> int:
+        n = C.c_uint64()
+        self._check(lib().mpc_stats_raw_len(self._h, C.byref(n)))
+        return int(n.value)
+
+    def stats_copy_raw_device(self, d_dst: int, stream: int = 0) -> None:
+        """Asynchronous device-to-device copy of the raw uint64 accumulators into ``d_dst``
+        (``stats_raw_len()`` words) on ``stream``: the operand of a device-side all-reduce."""
+        self._check(lib().mpc_stats_copy_raw_device(self._h, d_dst, stream or None))
+
+    def stats_from_raw(self, raw: np.ndarray) -> np.ndarray:
+        """Statistics vector (ABI layout) of a raw accumulator array, e.g. an all-reduced one."""
+        raw = np.ascontiguousarray(raw, dtype=np.uint64)
+        v = np.zeros(self.stats_len, dtype=np.uint64)
+        self._check(lib().mpc_stats_from_raw(self._h, raw.ctypes.data, raw.size, v.ctypes.data, v.size))
         return v
 
     def stats_merge(self, vec: np.ndarray) -> None:

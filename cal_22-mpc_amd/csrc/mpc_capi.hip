@@ -679,6 +679,31 @@ int mpc_stats_get(mpc_handle *h, uint64_t *vec, size_t n)
   return MPC_OK;
 }
 
+int mpc_stats_raw_len(const mpc_handle *h, uint64_t *raw_len)
+{
+  if (!h || !raw_len) return MPC_E_INVAL;
+  *raw_len = h->raw_len;
+  return MPC_OK;
+}
+
+int mpc_stats_copy_raw_device(mpc_handle *h, void *d_dst, void *hip_stream)
+{
+  if (!h || !d_dst) return MPC_E_INVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(d_dst, h->d_raw, h->raw_len * sizeof(u64), hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(hip_stream)));
+  return MPC_OK;
+}
+
+int mpc_stats_from_raw(const mpc_handle *h, const uint64_t *raw, size_t raw_len, uint64_t *vec, size_t n)
+{
+  if (!h || !raw || !vec || raw_len != h->raw_len || n < h->stats_len) return MPC_E_INVAL;
+  std::vector<u64> r(raw, raw + raw_len), out(h->stats_len, 0);
+  derive_stats(h, r, out);
+  std::memcpy(vec, out.data(), h->stats_len * sizeof(u64));
+  return MPC_OK;
+}
+
 int mpc_stats_merge(mpc_handle *h, const uint64_t *vec, size_t n)
 {
   if (!h || !vec || n != h->stats_len) return MPC_E_INVAL;

@@ -35,6 +35,20 @@ def all_reduce_stats(vec: np.ndarray, device=None) -> np.ndarray:
     return t.cpu().numpy().view(np.uint64)
 
 
+def all_reduce_raw_on_device(evaluator, scratch, stream: int = 0):
+    """Device-side form of the same collective: copy the evaluator's raw uint64 accumulators into
+    ``scratch`` (an int64 torch tensor of ``evaluator.stats_raw_len()`` elements on the evaluator's
+    GPU) on ``stream`` and SUM all-reduce it in place -- no host round trip, nothing waits.
+    ``evaluator.stats_from_raw(scratch.cpu().numpy().view(np.uint64))`` gives the statistics vector
+    when the host finally wants it.  ``stream`` must be torch's current stream."""
+    import torch.distributed as dist
+
+    evaluator.stats_copy_raw_device(scratch.data_ptr(), stream)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
+    return scratch
+
+
 def evaluate_sharded(evaluator, npy_path: str, rank: int, world: int, device=None, skip_last_row: bool = True):
     """Each rank streams its contiguous share of the rows of `npy_path` through
     `evaluator` (a ``VPC`` / ``BDI`` of this package bound to the rank's GPU), then

@@ -106,6 +106,17 @@ int mpc_stats_len(const mpc_handle *h, uint64_t *len);
 int mpc_stats_get(mpc_handle *h, uint64_t *vec, size_t n);      /* syncs */
 int mpc_stats_merge(mpc_handle *h, const uint64_t *vec, size_t n); /* += */
 int mpc_stats_set(mpc_handle *h, const uint64_t *vec, size_t n);   /* = (after an all-reduce) */
+
+/* Device-side exchange (multi-GPU without a host round trip).  The handle's device
+ * accumulators ("raw" statistics: VPC [sum_r(K)] [sum_r2(K)] [histogram(K x B)], BDI
+ * [Counts(9)] [compressed_bits]) are plain uint64 sums, so ranks may all-reduce them
+ * directly: mpc_stats_copy_raw_device enqueues an asynchronous device-to-device copy of
+ * the raw_len words into d_dst on hip_stream (after everything already enqueued there),
+ * and mpc_stats_from_raw turns such an array -- on the host, e.g. after the all-reduce --
+ * into the statistics vector described above (merged-in host statistics not included). */
+int mpc_stats_raw_len(const mpc_handle *h, uint64_t *raw_len);
+int mpc_stats_copy_raw_device(mpc_handle *h, void *d_dst, void *hip_stream);
+int mpc_stats_from_raw(const mpc_handle *h, const uint64_t *raw, size_t raw_len, uint64_t *vec, size_t n);
 int mpc_stats_reset(mpc_handle *h);
 
 /* ---- configuration check without a device --------------------------------

@@ -374,6 +374,20 @@ def test_device_resident_path_and_synth(mpc, oracle, configs, traces):
         sr, cr = o.compress(ref)
         assert (d_s.cpu().numpy().view(np.uint16) == sr).all() and (d_c.cpu().numpy() == cr).all()
         assert (ev.stats_vector() == o.stats_vector()).all()
+        # device-side exchange operand: raw accumulators copied on the stream, derived on the host
+        scratch = torch.zeros(ev.stats_raw_len(), dtype=torch.int64, device=dev)
+        ev.stats_copy_raw_device(scratch.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        raw = scratch.cpu().numpy().view(np.uint64)
+        assert (ev.stats_from_raw(raw) == o.stats_vector()).all()
+        assert (ev.stats_from_raw(raw * np.uint64(3))[:3] == o.stats_vector()[:3] * np.uint64(3)).all()   # sums of ranks
+    ev = mpc.BDI(64)
+    lines = traces.bdi_stress(2800, 64)
+    ev.compress_lines(lines)
+    scratch = torch.zeros(ev.stats_raw_len(), dtype=torch.int64, device=dev)
+    ev.stats_copy_raw_device(scratch.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert (ev.stats_from_raw(scratch.cpu().numpy().view(np.uint64)) == ev.stats_vector()).all()
 
 
 def test_full_size_properties(mpc, configs, golden_dir):
