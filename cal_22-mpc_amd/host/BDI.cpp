@@ -64,10 +64,12 @@ void BDI::CompressBatch(const uint8_t *lines, unsigned long long n)
   if (rc != MPC_OK) fail("BDI::CompressBatch", rc, m_Handle);
 }
 
-unsigned long long BDI::CompressFile(const std::string &npyPath)
+unsigned long long BDI::CompressFile(const std::string &tracePath)
 {
   uint64_t done = 0;
-  int rc = mpc_compress_npy(m_Handle, npyPath.c_str(), 0, ~0ull, 1, &done);
+  const bool isLog = tracePath.size() > 4 && tracePath.compare(tracePath.size() - 4, 4, ".log") == 0;
+  int rc = isLog ? mpc_compress_gpgpusim_log(m_Handle, tracePath.c_str(), nullptr, &done)
+                 : mpc_compress_npy(m_Handle, tracePath.c_str(), 0, ~0ull, 1, &done);
   if (rc != MPC_OK) fail("BDI::CompressFile", rc, m_Handle);
   return done;
 }

@@ -34,7 +34,7 @@ public:
   virtual unsigned CompressLine(std::vector<uint8_t> &dataLine);
   virtual CompResult *GetResult();
   virtual void CompressBatch(const uint8_t *lines, unsigned long long n);
-  virtual unsigned long long CompressFile(const std::string &npyPath);
+  virtual unsigned long long CompressFile(const std::string &tracePath);
   virtual unsigned GetLineSize() { return m_LineSize; }
 
 private:

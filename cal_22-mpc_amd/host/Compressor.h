@@ -32,9 +32,10 @@ public:
 
   // ADDITIVE: n consecutive lines of GetLineSize() bytes; statistics accumulate.
   virtual void CompressBatch(const uint8_t *lines, unsigned long long n) = 0;
-  // ADDITIVE: stream a C-order uint8 [N, L] .npy file (all rows but the last,
-  // as the reference driver does); returns the number of rows evaluated.
-  virtual unsigned long long CompressFile(const std::string &npyPath) = 0;
+  // ADDITIVE: stream a whole trace file through the evaluator: a C-order uint8 [N, L] .npy
+  // file (all rows but the last, as the reference driver does) or a GPGPU-Sim .log file (its
+  // GLOBAL_ACC_R / GLOBAL_ACC_W requests); returns the number of lines evaluated.
+  virtual unsigned long long CompressFile(const std::string &tracePath) = 0;
   virtual unsigned GetLineSize() = 0;
 
 protected:

@@ -9,8 +9,8 @@ namespace trace
 namespace gpgpusim
 {
 
-LoaderGPGPU::LoaderGPGPU(const char *filePath) : Loader(filePath), m_NumKeys(0), m_LineSize(0) { Reset(); }
-LoaderGPGPU::LoaderGPGPU(const std::string filePath) : Loader(filePath), m_NumKeys(0), m_LineSize(0) { Reset(); }
+LoaderGPGPU::LoaderGPGPU(const char *filePath) : Loader(filePath), m_NumKeys(0), m_LineSize(0), m_Untouched(true) { Reset(); }
+LoaderGPGPU::LoaderGPGPU(const std::string filePath) : Loader(filePath), m_NumKeys(0), m_LineSize(0), m_Untouched(true) { Reset(); }
 
 unsigned LoaderGPGPU::GetCachelineSize()
 {
@@ -56,6 +56,7 @@ bool LoaderGPGPU::readRecord(MemReqGPU_t &r)
 MemReq_t *LoaderGPGPU::GetCacheline(MemReq_t *memReq)
 {
   MemReqGPU_t *memReqGPU = static_cast<MemReqGPU_t *>(memReq);
+  m_Untouched = false;
   memReqGPU->isEnd = !readRecord(*memReqGPU);
   return memReq;
 }
@@ -80,6 +81,7 @@ unsigned long long LoaderGPGPU::GetBatch(uint8_t *dst, unsigned long long maxLin
   }
   MemReqGPU_t req;
   unsigned long long n = 0;
+  m_Untouched = false;
   while (n < maxLines) {
     if (!readRecord(req)) break;
     if (!isEvaluated((uint32_t)req.reqType)) continue;
@@ -100,6 +102,7 @@ void LoaderGPGPU::Reset()
   m_FileStream.clear();
   m_FileStream.seekg(0);
   isFileValid();
+  m_Untouched = true;
 }
 
 void LoaderGPGPU::isFileValid()

@@ -83,6 +83,8 @@ public:
   // ADDITIVE: the GLOBAL_ACC_R / GLOBAL_ACC_W lines of the records not yet delivered, packed
   virtual unsigned long long GetBatch(uint8_t *dst, unsigned long long maxLines);
   virtual bool SupportsBatch() { return true; }
+  // the library streams .log files itself (mpc_compress_gpgpusim_log) while nothing has been read yet
+  virtual std::string GetStreamablePath() { return m_Untouched ? m_FilePath : std::string(); }
 
   static bool isEvaluated(uint32_t reqType) { return reqType == GLOBAL_ACC_R || reqType == GLOBAL_ACC_W; }
 
@@ -93,6 +95,7 @@ private:
   uint8_t m_NumKeys;
   std::map<std::string, int> m_KeySizeList;
   unsigned m_LineSize;                 // cached by GetBatch
+  bool m_Untouched;                    // no record delivered since the last Reset()
 };
 
 }  // namespace gpgpusim
