@@ -5,10 +5,12 @@
 // computed by a gfx950 kernel in mpc_kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mpc_hip.h"
@@ -175,9 +177,59 @@ int create_vpc_from_text(const std::string &text, int device, mpc_handle **out)
   return MPC_OK;
 }
 
-// Workgroups per CU of the grid-stride VPC kernels.  4-5 are resident; a grid of 32 per CU
-// lets CUs that finish early pick up more work (same-box A/B against 8 per CU: random -3.5 %,
-// mixed -5 %, 128-byte lines -9 %; all-zero traces +3 %).
+// Staging copies (caller's buffer -> pinned slot) are memory-bandwidth work on the host: one
+// thread moves ~12-24 GB/s, less than the PCIe link takes, so large copies are split over a
+// few threads.
+constexpr size_t kCopySlice = 8u << 20;
+constexpr unsigned kCopyThreads = 4;
+
+void parallel_copy(void *dst, const void *src, size_t bytes)
+{
+  const size_t want = (bytes + kCopySlice - 1) / kCopySlice;
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  const unsigned nt = (unsigned)std::min<size_t>(std::min<size_t>(want, kCopyThreads), hw);
+  if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+  const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
+  std::vector<std::thread> th;
+  for (unsigned i = 0; i < nt; i++) {
+    const size_t off = (size_t)i * per;
+    if (off >= bytes) break;
+    const size_t n = std::min(per, bytes - off);
+    th.emplace_back([=]() { std::memcpy((char *)dst + off, (const char *)src + off, n); });
+  }
+  for (auto &t : th) t.join();
+}
+
+// the same for page cache -> pinned slot; false on a short read / error
+bool parallel_pread(int fd, void *dst, size_t bytes, u64 file_off)
+{
+  const size_t want = (bytes + kCopySlice - 1) / kCopySlice;
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(want, kCopyThreads), hw));
+  const size_t per = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
+  std::vector<int> ok(nt, 1);
+  auto work = [&](unsigned i) {
+    size_t off = (size_t)i * per;
+    const size_t end = std::min(bytes, off + per);
+    while (off < end) {
+      const ssize_t got = pread(fd, (char *)dst + off, end - off, (off_t)(file_off + off));
+      if (got <= 0) { ok[i] = 0; return; }
+      off += (size_t)got;
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned i = 1; i < nt; i++) th.emplace_back(work, i);
+  work(0);
+  for (auto &t : th) t.join();
+  for (int v : ok) if (!v) return false;
+  return true;
+}
+
+// Workgroups per CU of the grid-stride VPC and BDI kernels.  2-8 are resident; a grid of 32 per
+// CU lets CUs that finish early pick up more work (same-box A/B against 8 per CU: VPC random
+// -3.5 %, mixed -5 %, 128-byte lines -9 %, all-zero traces +3 %; BDI random -8 %, pointers -10 %).
 constexpr int kWgPerCu = 32;
 
 int grid_for(const mpc_handle *h, u64 work_items, int block, int per_cu)
@@ -477,7 +529,7 @@ int mpc_compress_batch(mpc_handle *h, const uint8_t *lines, uint64_t n, uint16_t
     rc = retire(h, s);   // the slot's previous chunk (overlapped with the other slot's work)
     if (rc != MPC_OK) return rc;
     const u64 take = (n - done) < (u64)h->stage_lines ? (n - done) : (u64)h->stage_lines;
-    std::memcpy(s.h_in, lines + done * (u64)h->L, take * (u64)h->L);
+    parallel_copy(s.h_in, lines + done * (u64)h->L, (size_t)(take * (u64)h->L));
     rc = submit(h, s, take, sizes ? sizes + done : nullptr, sel ? sel + done : nullptr);
     if (rc != MPC_OK) return rc;
     done += take;
@@ -523,7 +575,7 @@ int mpc_compress_npy(mpc_handle *h, const char *path, uint64_t first_row, uint64
   if (hipSetDevice(h->device) != hipSuccess) { fclose(f); return set_err(h, MPC_E_HIP, "hipSetDevice failed"); }
   rc = ensure_slots(h);
   if (rc != MPC_OK) { fclose(f); return rc; }
-  if (fseeko(f, (off_t)(off + begin * cols), SEEK_SET) != 0) { fclose(f); return set_err(h, MPC_E_INVAL, "seek failed"); }
+  const int fd = fileno(f);
   u64 done = begin;
   int which = 0;
   while (done < end) {
@@ -531,7 +583,7 @@ int mpc_compress_npy(mpc_handle *h, const char *path, uint64_t first_row, uint64
     rc = retire(h, s);
     if (rc != MPC_OK) break;
     const u64 take = (end - done) < (u64)h->stage_lines ? (end - done) : (u64)h->stage_lines;
-    if (fread(s.h_in, (size_t)cols, (size_t)take, f) != (size_t)take) { rc = set_err(h, MPC_E_PARSE, "short read: .npy file is truncated"); break; }
+    if (!parallel_pread(fd, s.h_in, (size_t)(take * cols), off + done * cols)) { rc = set_err(h, MPC_E_PARSE, "short read: .npy file is truncated"); break; }
     rc = submit(h, s, take, nullptr, nullptr);
     if (rc != MPC_OK) break;
     done += take;
