@@ -235,9 +235,6 @@ constexpr int kWgPerCu = 32;
 int grid_for(const mpc_handle *h, u64 work_items, int block, int per_cu)
 {
   u64 need = (work_items + (u64)block - 1) / (u64)block;
-#ifdef MPC_DEV_GRID
-  if (const char *e = getenv("MPC_DEV_WG_PER_CU")) per_cu = atoi(e);
-#endif
   u64 cap = (u64)h->num_cus * (u64)per_cu;
   if (need < 1) need = 1;
   return (int)(need < cap ? need : cap);

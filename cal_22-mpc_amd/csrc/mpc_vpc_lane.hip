@@ -623,15 +623,7 @@ __device__ __forceinline__ void lane_fetch(uint4 (&v)[NQ], const uint4 *__restri
   // clamped: past the end it re-reads the last line (never evaluated: `valid` is false there)
   const uint4 *src = lines + (u64)min(line, n_lines - 1u) * NQ;
 #pragma unroll
-  for (int i = 0; i < NQ; i++) {
-#ifdef MPC_DEV_NT
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    const u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(src + i));
-    v[i] = make_uint4(q.x, q.y, q.z, q.w);
-#else
-    v[i] = src[i];
-#endif
-  }
+  for (int i = 0; i < NQ; i++) v[i] = src[i];
 }
 
 // n_lines < 2^31 per launch (the host splits larger batches)
@@ -752,19 +744,7 @@ extern "C" size_t mpc_vpc_lane_smem(const MpcVpcParams *P) { return vpc_stats_sm
 extern "C" hipError_t mpc_launch_vpc_lane(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
                                           int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
 {
-  size_t smem = mpc_vpc_lane_smem(P);
-#ifdef MPC_DEV_LDS_PAD
-  if (const char *e = getenv("MPC_DEV_LDS_PAD")) {   // development: limit the waves per SIMD through the LDS footprint
-    smem += (size_t)atoi(e);
-    static bool once = false;
-    if (!once) {
-      once = true;
-#define X(...) hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_lane_kernel<16, false, __VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      MPC_LANE_SEQUENCES(X)
-#undef X
-    }
-  }
-#endif
+  const size_t smem = mpc_vpc_lane_smem(P);
   const u64 max_lines = 1ull << 30;     // 32-bit line indices inside the kernel
   for (u64 done = 0; done < n_lines; done += max_lines) {
     const u64 take = (n_lines - done) < max_lines ? (n_lines - done) : max_lines;
