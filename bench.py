@@ -50,7 +50,7 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0, 
            "zeros": traces.zeros, "pointers_u64": traces.pointers_u64}[kind]
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     cfg = configs.probe_config(L)
-    make = (lambda: O.VpcOracle(cfg)) if algo == "VPC" else (lambda: O.BdiOracle(L))
+    make = {"VPC": lambda: O.VpcOracle(cfg), "BDI": lambda: O.BdiOracle(L), "FPC": lambda: O.FpcOracle(L)}[algo]
     # calibrate on a short run, then size the sample for ~`seconds` of wall time
     cal_n = 4096
     cal = gen(cal_n, L)
@@ -70,7 +70,7 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0, 
     dt = time.perf_counter() - t0
     return {"value": cores * per_thread / dt, "unit": "blocks/s", "cores": cores, "kind": "port",
             "sample": f"{per_thread} {workload} {L} B blocks per thread x {cores} threads "
-                      f"(oracle/mpc_oracle.c, {'probe config' if algo == 'VPC' else 'BDI'}), {dt:.1f} s",
+                      f"(oracle/mpc_oracle.c, {'probe config' if algo == 'VPC' else algo}), {dt:.1f} s",
             "single_core_blocks_per_s": rate1}
 
 
@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="random_u32", choices=sorted(WORKLOADS))
     ap.add_argument("--lines", type=int, default=256 << 20, help="blocks per GPU (default 256 Mi = 16 GiB at 64 B)")
-    ap.add_argument("--algo", default="VPC", choices=["VPC", "BDI"])
+    ap.add_argument("--algo", default="VPC", choices=["VPC", "BDI", "FPC"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-single-gpu", action="store_true",
                     help="development: run the N>1 code path with every rank on cuda:0 and the gloo backend "
@@ -124,8 +124,10 @@ def main():
     torch.cuda.synchronize()
     if args.algo == "VPC":
         ev = mpc.VPC(configs.probe_config(L), device=local_rank)
-    else:
+    elif args.algo == "BDI":
         ev = mpc.BDI(L, device=local_rank)
+    else:
+        ev = mpc.FPC(L, device=local_rank)
     # a real (non-default) stream: the kernel is launched on it through the C ABI and
     # the HIP events that time it are recorded on the same stream
     stream = torch.cuda.Stream(device=dev)
@@ -189,6 +191,8 @@ def main():
 
     if args.algo == "BDI":
         kernel_name = f"bdi_kernel<{L // 4}>"
+    elif args.algo == "FPC":
+        kernel_name = f"fpc_kernel<{L // 4}>"
     elif ev.kernel_path == mpc.MPC_PATH_VPC_FAST:
         kernel_name = f"vpc_lane_kernel<{L // 4}>"        # one lane per line, W = L/4 words
     else:

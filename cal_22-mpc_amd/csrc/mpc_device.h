@@ -65,3 +65,5 @@ struct MpcVpcParams {
  *   BDI: [0,9) Counts  [9] compressed_bits                                   */
 static inline uint64_t mpc_vpc_raw_len(int K, int bins) { return 2ull * (uint64_t)K + (uint64_t)K * (uint64_t)bins; }
 #define MPC_BDI_RAW_LEN 10
+/*   FPC: [0,8) Counts (Prefix0..7)  [8] compressed_bits                        */
+#define MPC_FPC_RAW_LEN 9

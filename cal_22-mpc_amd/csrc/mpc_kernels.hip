@@ -3,6 +3,7 @@
 //
 //   vpc_generic_kernel     VPC, any configuration the reference can run
 //   bdi_kernel             BDI baseline (reference src/compressor/BDI.cpp)
+//   fpc_kernel             FPC baseline (reference src/compressor/FPC.cpp)
 //   synth_kernel / read_probe_kernel   measurement helpers
 #include "mpc_kernel_common.h"
 
@@ -411,6 +412,83 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// FPC (reference FPC.cpp:7-88): frequent pattern compression of the line's 32-bit
+// little-endian words; one lane per line, line in registers.  The sign-extension tests of
+// the reference are range tests: (v & 0xFFFFFFF8) in {0, 0xFFFFFFF8}  <=>  v + 8 < 16, etc.
+// A zero run costs 3 + 3 bits once, its further words nothing (FPC.cpp:20-32); a run ends
+// at the end of the line (the reference reads past it there: undefined behaviour, see
+// DESIGN.md "Deliberate deviations").  Per-lane counters are 16-bit fields of two 64-bit
+// registers, flushed to LDS every 1024 lines.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 fpc_prefix(u32 v)
+{
+  const u32 lo = v & 0xffffu, hi = v >> 16;
+  const bool t4 = v + 8u < 16u, t8 = v + 128u < 256u, t16 = v + 32768u < 65536u;
+  const bool halves = (((lo + 128u) & 0xffffu) < 256u) && (((hi + 128u) & 0xffffu) < 256u);
+  const bool rep = v == (v & 0xffu) * 0x01010101u;
+  return v == 0u ? 0u : t4 ? 1u : t8 ? 2u : t16 ? 3u : lo == 0u ? 4u : halves ? 5u : rep ? 6u : 7u;
+}
+
+__device__ __forceinline__ void fpc_flush(u64 &even, u64 &odd, u64 &bits, u64 *s_counts)
+{
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const u64 e = (even >> (16 * k)) & 0xffffull, o = (odd >> (16 * k)) & 0xffffull;
+    if (e) atomicAdd(&s_counts[2 * k], e);
+    if (o) atomicAdd(&s_counts[2 * k + 1], o);
+  }
+  if (bits) atomicAdd(&s_counts[8], bits);
+  even = odd = bits = 0;
+}
+
+template <int NW>   // words per line
+__global__ void __launch_bounds__(256)
+fpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ sizes_out,
+           int8_t *__restrict__ sel_out, u64 *gstats)
+{
+  __shared__ u64 s_counts[MPC_FPC_RAW_LEN];
+  if (threadIdx.x < MPC_FPC_RAW_LEN) s_counts[threadIdx.x] = 0;
+  __syncthreads();
+  // bits per prefix, 6 bits each: 6, 7, 11, 19, 19, 19, 11, 35 (PREFIX_SIZE + payload, FPC.h:8 + FPC.cpp)
+  constexpr u64 kBits = 6ull | (7ull << 6) | (11ull << 12) | (19ull << 18) | (19ull << 24) | (19ull << 30) |
+                        (11ull << 36) | (35ull << 42);
+  u64 even = 0, odd = 0, bits_acc = 0;   // counts of prefixes 0,2,4,6 / 1,3,5,7 in 16-bit fields; compressed bits
+  u32 since_flush = 0;
+  for (u64 line = (u64)blockIdx.x * blockDim.x + threadIdx.x; line < n_lines; line += (u64)gridDim.x * blockDim.x) {
+    u32 w[NW];
+    const uint4 *src = lines + line * (NW / 4);
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) {
+      const uint4 q = src[i];
+      w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+    }
+    u64 lc = 0;          // this line's counts, 8-bit field per prefix (at most NW <= 64 each)
+    u32 size = 0;
+    bool prev_zero = false;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      const u32 p = fpc_prefix(w[i]);
+      const u32 b = (u32)(kBits >> (6u * p)) & 63u;
+      size += (p == 0u && prev_zero) ? 0u : b;
+      prev_zero = p == 0u;
+      lc += 1ull << (8u * p);
+    }
+    even += lc & 0x00ff00ff00ff00ffull;
+    odd += (lc >> 8) & 0x00ff00ff00ff00ffull;
+    bits_acc += size;
+    if (sizes_out) sizes_out[line] = (uint16_t)size;
+    if (sel_out) sel_out[line] = 0;
+    if (++since_flush == 1023u) {       // 1023 lines x 64 words < 2^16 per field
+      fpc_flush(even, odd, bits_acc, s_counts);
+      since_flush = 0;
+    }
+  }
+  fpc_flush(even, odd, bits_acc, s_counts);
+  __syncthreads();
+  if (threadIdx.x < MPC_FPC_RAW_LEN && s_counts[threadIdx.x]) atomicAdd(&gstats[threadIdx.x], s_counts[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
 // measurement helpers
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ u64 splitmix64(u64 x)
@@ -479,6 +557,19 @@ extern "C" hipError_t mpc_launch_bdi(const void *d_lines, u64 n_lines, int L, ui
   case 32: hipLaunchKernelGGL(bdi_kernel<8>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   case 64: hipLaunchKernelGGL(bdi_kernel<16>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   case 128: hipLaunchKernelGGL(bdi_kernel<32>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
+  default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mpc_launch_fpc(const void *d_lines, u64 n_lines, int L, uint16_t *d_sizes, int8_t *d_sel,
+                                     u64 *d_stats, int grid, hipStream_t stream)
+{
+  const uint4 *l = static_cast<const uint4 *>(d_lines);
+  switch (L) {
+  case 32: hipLaunchKernelGGL(fpc_kernel<8>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
+  case 64: hipLaunchKernelGGL(fpc_kernel<16>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
+  case 128: hipLaunchKernelGGL(fpc_kernel<32>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -1,7 +1,7 @@
 // main.cpp -- the `compressor` command line of the reference (src/main.cpp), kept
 // flag-for-flag:  compressor -a ALGO -i TRACE [-c CONFIG.json] [-o OUTDIR] [-h]
 // stdout "comp.ratio: <double>", CSV rows appended to OUTDIR/<stem>_results.csv and
-// OUTDIR/<stem>_results_detail.csv.  This build evaluates VPC and BDI (the hot path
+// OUTDIR/<stem>_results_detail.csv.  This build evaluates VPC, BDI and FPC (the hot path
 // of SURVEY.md section 8) on the MI355X; traces are .npy files or GPGPU-Sim .log
 // files (GLOBAL_ACC_R / GLOBAL_ACC_W requests, reference main.cpp:222-224).  The other
 // algorithm names and the APSim .txt format are recognised and reported as not part
@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "BDI.h"
+#include "FPC.h"
 #include "LoaderGPGPU.h"
 #include "LoaderNPY.h"
 #include "VPC.h"
@@ -108,9 +109,11 @@ int main(int argc, char **argv)
     compressor = new comp::VPC(configPath);
   } else if (algorithm == "BDI") {
     compressor = new comp::BDI(lineSize);
-  } else if (algorithm == "FPC" || algorithm == "BPC" || algorithm == "CPACK" || algorithm == "SC2" ||
+  } else if (algorithm == "FPC") {
+    compressor = new comp::FPC(lineSize);
+  } else if (algorithm == "BPC" || algorithm == "CPACK" || algorithm == "SC2" ||
              algorithm == "PATTERN" || algorithm == "VIEWER") {
-    std::cout << "Algorithm " << algorithm << " is not part of this build: VPC and BDI are (see DESIGN.md, \"Out of scope\")."
+    std::cout << "Algorithm " << algorithm << " is not part of this build: VPC, BDI and FPC are (see DESIGN.md, \"Out of scope\")."
               << std::endl;
     return 1;
   } else {

@@ -453,3 +453,65 @@ void mpc_o_bdi_batch(const uint8_t *lines, int L, uint64_t n, uint16_t *sizes,
     if (selected) selected[i] = (int8_t)sel;
   }
 }
+
+/* ---------------------------------------------------------------------------
+ * FPC (reference src/compressor/FPC.cpp:7-88, FPC.h:31-38).  Words are little
+ * endian (concatenate(), FPC.cpp:90-108); the tests run in the reference's order.
+ * ------------------------------------------------------------------------- */
+static int fpc_prefix(uint32_t val)
+{
+  if (val == 0u) return 0;
+  if ((val & 0xFFFFFFF8u) == 0u || (val & 0xFFFFFFF8u) == 0xFFFFFFF8u) return 1;      /* 4-bit sign-extended   */
+  if ((val & 0xFFFFFF80u) == 0u || (val & 0xFFFFFF80u) == 0xFFFFFF80u) return 2;      /* 8-bit sign-extended   */
+  if ((val & 0xFFFF8000u) == 0u || (val & 0xFFFF8000u) == 0xFFFF8000u) return 3;      /* 16-bit sign-extended  */
+  if ((val & 0x0000FFFFu) == 0u) return 4;                                            /* halfword + zero pad   */
+  {
+    const uint32_t m = val & 0xFF80FF80u;                                             /* two byte-sized halves */
+    if (m == 0u || m == 0xFF800000u || m == 0x0000FF80u || m == 0xFF80FF80u) return 5;
+  }
+  if ((val & 0xFFu) == ((val >> 8) & 0xFFu) && (val & 0xFFu) == ((val >> 16) & 0xFFu) &&
+      (val & 0xFFu) == ((val >> 24) & 0xFFu)) return 6;                               /* repeated bytes        */
+  return 7;
+}
+
+unsigned mpc_o_fpc_line(const uint8_t *line, int L, mpc_o_fpc_stats *st)
+{
+  static const unsigned kBits[8] = {3 + 3, 4 + 3, 8 + 3, 16 + 3, 16 + 3, 16 + 3, 8 + 3, 32 + 3};   /* + PREFIX_SIZE */
+  const int n = L / 4;
+  unsigned size = 0;
+  int i = 0;
+  while (i < n) {
+    const uint32_t val = (uint32_t)line[4 * i] | ((uint32_t)line[4 * i + 1] << 8) | ((uint32_t)line[4 * i + 2] << 16) |
+                         ((uint32_t)line[4 * i + 3] << 24);
+    const int p = fpc_prefix(val);
+    unsigned bits = kBits[p];
+    if (p == 0 && i > 0) {
+      /* words after the first of a zero run cost nothing (FPC.cpp:26-30) */
+      const uint32_t prev = (uint32_t)line[4 * i - 4] | ((uint32_t)line[4 * i - 3] << 8) |
+                            ((uint32_t)line[4 * i - 2] << 16) | ((uint32_t)line[4 * i - 1] << 24);
+      if (prev == 0u) bits = 0;
+    }
+    size += bits;
+    if (st) {
+      st->original_bits += 32;
+      st->compressed_bits += bits;
+      st->total_words++;
+      st->counts[p]++;
+    }
+    i++;
+  }
+  if (st) {
+    st->lines++;
+    st->comp_ratio = (double)st->original_bits / (double)st->compressed_bits;
+  }
+  return size;
+}
+
+void mpc_o_fpc_batch(const uint8_t *lines, int L, uint64_t n, uint16_t *sizes, mpc_o_fpc_stats *st)
+{
+  for (uint64_t i = 0; i < n; i++) {
+    const unsigned s = mpc_o_fpc_line(lines + i * (uint64_t)L, L, st);
+    if (sizes) sizes[i] = (uint16_t)s;
+  }
+}
+

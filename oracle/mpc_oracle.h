@@ -133,6 +133,24 @@ void mpc_o_bdi_batch(const uint8_t *lines, int L, uint64_t n, uint16_t *sizes,
 uint64_t mpc_o_bdi_reduce_sign(uint64_t x);
 unsigned mpc_o_bdi_check(const uint8_t *line, int L, unsigned base_size, unsigned delta_size);
 
+/* FPC::CompressLine (FPC.cpp:7-88), frequent pattern compression of the line's L/4
+ * little-endian 32-bit words.  PARITY UNPINNED: the reference ships no fixture for it and
+ * FPC.cpp does not compile here without the un-vendored strutil.h, so this follows the
+ * source text only.  One deliberate definition: the zero-run loop of the reference
+ * (`while(dataConcat[i] == 0)`, FPC.cpp:26) reads past the end of the line when the run
+ * reaches it (undefined behaviour, the result depends on heap contents); here a run ends
+ * at the end of the line.                                                          */
+typedef struct {
+  uint64_t lines;
+  uint64_t original_bits;     /* 32 per word (FPC.h:31-38) */
+  uint64_t compressed_bits;
+  double   comp_ratio;
+  uint64_t total_words;
+  uint64_t counts[8];         /* FPCState Prefix0..7 */
+} mpc_o_fpc_stats;
+unsigned mpc_o_fpc_line(const uint8_t *line, int L, mpc_o_fpc_stats *st);
+void mpc_o_fpc_batch(const uint8_t *lines, int L, uint64_t n, uint16_t *sizes, mpc_o_fpc_stats *st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,13 @@ class OBdiStats(C.Structure):
     ]
 
 
+class OFpcStats(C.Structure):
+    _fields_ = [
+        ("lines", C.c_uint64), ("original_bits", C.c_uint64), ("compressed_bits", C.c_uint64),
+        ("comp_ratio", C.c_double), ("total_words", C.c_uint64), ("counts", C.c_uint64 * 8),
+    ]
+
+
 def build(ref: bool = True) -> None:
     """Compile the oracle (and oracle/_ref when /root/reference is mounted)."""
     subprocess.run(["make", "-s", "-C", HERE, "all"], check=True)
@@ -105,6 +112,8 @@ def lib() -> C.CDLL:
         L.mpc_o_bdi_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p,
                                       C.POINTER(OBdiStats)]
         L.mpc_o_bdi_batch.restype = None
+        L.mpc_o_fpc_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(OFpcStats)]
+        L.mpc_o_fpc_batch.restype = None
         L.mpc_o_bdi_reduce_sign.argtypes = [C.c_uint64]
         L.mpc_o_bdi_reduce_sign.restype = C.c_uint64
         L.mpc_o_bdi_check.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint]
@@ -261,3 +270,29 @@ class BdiOracle:
     def stats_vector(self) -> np.ndarray:
         return np.array([self.st.lines, self.st.original_bits, self.st.compressed_bits]
                         + [self.st.counts[i] for i in range(9)], dtype=np.uint64)
+
+
+class FpcOracle:
+    """FPC::CompressLine restatement (reference FPC.cpp:7-88) -- PARITY UNPINNED, see mpc_oracle.h."""
+
+    def __init__(self, line_size: int):
+        if line_size % 4 or line_size < 4 or line_size > MAX_LINE:
+            raise ValueError("FPC needs a line size that is a multiple of 4")
+        self.L = line_size
+        self.reset()
+
+    def reset(self) -> None:
+        self.st = OFpcStats()
+
+    def compress(self, lines: np.ndarray, stats: bool = True) -> np.ndarray:
+        lines = np.ascontiguousarray(lines, dtype=np.uint8)
+        assert lines.ndim == 2 and lines.shape[1] == self.L
+        n = lines.shape[0]
+        sizes = np.zeros(n, dtype=np.uint16)
+        lib().mpc_o_fpc_batch(lines.ctypes.data, self.L, n, sizes.ctypes.data, C.byref(self.st) if stats else None)
+        return sizes
+
+    def stats_vector(self) -> np.ndarray:
+        return np.array([self.st.lines, self.st.original_bits, self.st.compressed_bits]
+                        + [self.st.counts[i] for i in range(8)], dtype=np.uint64)
+

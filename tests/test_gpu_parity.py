@@ -246,6 +246,35 @@ def test_bdi(mpc, oracle, traces, L):
         assert (s == 564).all() and (sel == 4).all()
 
 
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_fpc(mpc, oracle, traces, L):
+    """FPC baseline against the oracle's source-reading restatement (parity unpinned: the
+    reference has no fixture for it): every prefix, zero runs of every length incl. to the end of
+    the line, sign-extension boundaries."""
+    rng = np.random.default_rng(L)
+    n = 6000
+    special = np.array([0, 1, 7, 8, 0xFFFFFFF8, 0xFFFFFFF7, 0x7F, 0x80, 0xFFFFFF80, 0xFFFFFF7F, 0x7FFF, 0x8000,
+                        0xFFFF8000, 0xFFFF7FFF, 0x10000, 0x12340000, 0x007F007F, 0xFF80FF80, 0x0080007F, 0xFF7FFF80,
+                        0x007FFF80, 0xFF80007F, 0xABABABAB, 0x00000100, 0x01010101, 0x12345678, 0xFFFFFFFF, 0x80000000],
+                       dtype=np.uint32)
+    words = special[rng.integers(0, len(special), (n, L // 4))]
+    words[rng.random((n, L // 4)) < 0.35] = 0                      # zero runs
+    words[::7, -3:] = 0                                            # runs that reach the end of the line
+    words[1::7, :] = 0
+    lines = np.concatenate([words.astype("<u4").view(np.uint8).reshape(n, L), traces.structured(3000, L),
+                            traces.mixed(1000, L), traces.random_u32(500, L), traces.zeros(50, L)])
+    ev, o = mpc.FPC(L), oracle.FpcOracle(L)
+    assert ev.kernel_path == mpc.MPC_PATH_FPC
+    s_ref = o.compress(lines)
+    s, sel = ev.compress_lines(lines)
+    bad = np.nonzero(s != s_ref)[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}: {s[bad[:5]]} vs {s_ref[bad[:5]]}"
+    assert (sel == 0).all()
+    assert (ev.stats_vector() == o.stats_vector()).all()
+    assert (o.stats_vector()[3:] > 0).all()                        # every prefix occurs
+    assert ev.result()["comp_ratio"] == o.st.comp_ratio and ev.result()["total_words"] == o.st.total_words
+
+
 def test_edge_cases(mpc, oracle, configs, traces):
     cfg = configs.probe_config(64)
     ev = mpc.VPC(cfg)

@@ -222,3 +222,22 @@ def test_bdi_screen_stress_trace_reaches_every_outcome(oracle, traces):
         _, sel = o.compress(traces.bdi_screen_stress(4800, L))
         assert set(np.unique(sel)) >= {2, 3, 4, 5, 6, 7, 8}, (L, np.unique(sel))
 
+
+def test_kat_fpc_by_hand(oracle):
+    """FPC sizes worked out by hand from FPC.cpp:16-84 (prefix 3 bits + payload; a zero run costs 6
+    bits once).  The reference ships no fixture for FPC: these pin the restatement to the source
+    reading only."""
+    o = oracle.FpcOracle(64)
+
+    def size(words):
+        return int(o.compress(np.array(words, dtype="<u4").view(np.uint8).reshape(1, -1))[0])
+    assert size([0] * 16) == 6
+    assert size([5] * 16) == 16 * 7 and size([0xFFFFFFF9] * 16) == 16 * 7
+    assert size([100] * 16) == 16 * 11 and size([0xFFFFFF80] * 16) == 16 * 11
+    assert size([1000] * 16) == 16 * 19 and size([0x12340000] * 16) == 16 * 19
+    assert size([0x007F0001] * 16) == 16 * 19 and size([0xFF80FF81] * 16) == 16 * 19
+    assert size([0xABABABAB] * 16) == 16 * 11 and size([0x12345678] * 16) == 16 * 35
+    assert size([0, 0, 5, 0, 0, 0, 7, 0] + [0x12345678] * 8) == 6 + 7 + 6 + 7 + 6 + 8 * 35
+    assert size([1] + [0] * 15) == 7 + 6                 # a run that reaches the end of the line
+    assert o.st.total_words == 13 * 16 and sum(o.st.counts) == 13 * 16
+
