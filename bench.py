@@ -50,7 +50,7 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0, 
            "zeros": traces.zeros, "pointers_u64": traces.pointers_u64}[kind]
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     cfg = configs.probe_config(L)
-    make = {"VPC": lambda: O.VpcOracle(cfg), "BDI": lambda: O.BdiOracle(L), "FPC": lambda: O.FpcOracle(L)}[algo]
+    make = {"VPC": lambda: O.VpcOracle(cfg), "BDI": lambda: O.BdiOracle(L), "FPC": lambda: O.FpcOracle(L), "BPC": lambda: O.BpcOracle(L)}[algo]
     # calibrate on a short run, then size the sample for ~`seconds` of wall time
     cal_n = 4096
     cal = gen(cal_n, L)
@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="random_u32", choices=sorted(WORKLOADS))
     ap.add_argument("--lines", type=int, default=256 << 20, help="blocks per GPU (default 256 Mi = 16 GiB at 64 B)")
-    ap.add_argument("--algo", default="VPC", choices=["VPC", "BDI", "FPC"])
+    ap.add_argument("--algo", default="VPC", choices=["VPC", "BDI", "FPC", "BPC"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-single-gpu", action="store_true",
                     help="development: run the N>1 code path with every rank on cuda:0 and the gloo backend "
@@ -126,8 +126,10 @@ def main():
         ev = mpc.VPC(configs.probe_config(L), device=local_rank)
     elif args.algo == "BDI":
         ev = mpc.BDI(L, device=local_rank)
-    else:
+    elif args.algo == "FPC":
         ev = mpc.FPC(L, device=local_rank)
+    else:
+        ev = mpc.BPC(L, device=local_rank)
     # a real (non-default) stream: the kernel is launched on it through the C ABI and
     # the HIP events that time it are recorded on the same stream
     stream = torch.cuda.Stream(device=dev)
@@ -193,6 +195,8 @@ def main():
         kernel_name = f"bdi_kernel<{L // 4}>"
     elif args.algo == "FPC":
         kernel_name = f"fpc_kernel<{L // 4}>"
+    elif args.algo == "BPC":
+        kernel_name = f"bpc_kernel<{L // 4}>"
     elif ev.kernel_path == mpc.MPC_PATH_VPC_FAST:
         kernel_name = f"vpc_lane_kernel<{L // 4}>"        # one lane per line, W = L/4 words
     else:

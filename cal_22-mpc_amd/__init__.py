@@ -23,7 +23,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPC_HIP_LIB") or os.path.join(HERE, "libmpc_hip.so")   # override: development builds only
 
-MPC_PATH_VPC_FAST, MPC_PATH_VPC_GENERIC, MPC_PATH_BDI, MPC_PATH_FPC = 1, 2, 3, 4
+MPC_PATH_VPC_FAST, MPC_PATH_VPC_GENERIC, MPC_PATH_BDI, MPC_PATH_FPC, MPC_PATH_BPC = 1, 2, 3, 4, 5
 SYNTH_KINDS = {"zeros": 0, "random_u32": 1, "sine_f32": 2, "mixed": 3, "pointers_u64": 4}
 
 
@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
             "mpc_create_vpc_from_string": ([C.c_char_p, C.c_int, C.POINTER(H)], C.c_int),
             "mpc_create_bdi": ([C.c_uint, C.c_int, C.POINTER(H)], C.c_int),
             "mpc_create_fpc": ([C.c_uint, C.c_int, C.POINTER(H)], C.c_int),
+            "mpc_create_bpc": ([C.c_uint, C.c_int, C.POINTER(H)], C.c_int),
             "mpc_destroy": ([H], None),
             "mpc_get_info": ([H, C.POINTER(Info)], C.c_int),
             "mpc_last_error": ([H], C.c_char_p),
@@ -106,7 +107,7 @@ def lib() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = [
-    "mpc_create_vpc", "mpc_create_vpc_from_string", "mpc_create_bdi", "mpc_create_fpc", "mpc_destroy", "mpc_get_info",
+    "mpc_create_vpc", "mpc_create_vpc_from_string", "mpc_create_bdi", "mpc_create_fpc", "mpc_create_bpc", "mpc_destroy", "mpc_get_info",
     "mpc_last_error", "mpc_compress_batch", "mpc_compress_batch_device", "mpc_sync", "mpc_stats_len",
     "mpc_stats_get", "mpc_stats_merge", "mpc_stats_set", "mpc_stats_reset", "mpc_stats_raw_len",
     "mpc_stats_copy_raw_device", "mpc_stats_from_raw", "mpc_config_describe",
@@ -292,6 +293,24 @@ class FPC(_Evaluator):
         return {"lines": int(v[0]), "original_bits": int(v[1]), "compressed_bits": int(v[2]),
                 "comp_ratio": (float(v[1]) / float(v[2])) if v[2] else 0.0,
                 "total_words": int(v[3:11].sum()), "counts": [int(x) for x in v[3:11]]}
+
+
+class BPC(_Evaluator):
+    """``comp::BPC(lineSize)`` (reference ``BPC.h:90-107``); per-line ``selected`` is always 0."""
+
+    def __init__(self, line_size: int, device: int = -1):
+        super().__init__()
+        rc = lib().mpc_create_bpc(line_size, device, C.byref(self._h))
+        if rc != 0:
+            raise MpcError(rc, (lib().mpc_last_error(None) or b"").decode())
+        self._finish()
+        self.kernel_path = self.info.kernel_path
+
+    def result(self) -> Dict:
+        v = self.stats_vector()
+        return {"lines": int(v[0]), "original_bits": int(v[1]), "compressed_bits": int(v[2]),
+                "comp_ratio": (float(v[1]) / float(v[2])) if v[2] else 0.0,
+                "total_words": int(v[3]), "counts": [int(x) for x in v[4:11]]}
 
 
 def vpc_result_from_vector(v: np.ndarray, M: int, bins: int, L: int) -> Dict:

@@ -28,6 +28,7 @@ extern "C" {
 hipError_t mpc_launch_vpc_generic(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
 hipError_t mpc_launch_bdi(const void *, u64, int, uint16_t *, int8_t *, u64 *, int, hipStream_t);
 hipError_t mpc_launch_fpc(const void *, u64, int, uint16_t *, int8_t *, u64 *, int, hipStream_t);
+hipError_t mpc_launch_bpc(const void *, u64, int, uint16_t *, int8_t *, u64 *, int, hipStream_t);
 hipError_t mpc_launch_synth(void *, u64, unsigned, int, u64, u64, const uint32_t *, hipStream_t);
 hipError_t mpc_launch_read_probe(const void *, u64, uint32_t *, int, hipStream_t);
 hipError_t mpc_launch_vpc_lane(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
@@ -58,7 +59,7 @@ struct Slot {
 }  // namespace
 
 struct mpc_handle {
-  int algorithm = 0;   // 0 VPC, 1 BDI, 2 FPC
+  int algorithm = 0;   // 0 VPC, 1 BDI, 2 FPC, 3 BPC
   int device = 0;
   int L = 0;
   int num_cus = 256;
@@ -245,7 +246,9 @@ int launch(mpc_handle *h, const void *d_lines, u64 n, uint16_t *d_sizes, int8_t 
 {
   if (n == 0) return MPC_OK;
   hipError_t e;
-  if (h->algorithm == 2) {
+  if (h->algorithm == 3) {
+    e = mpc_launch_bpc(d_lines, n, h->L, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
+  } else if (h->algorithm == 2) {
     e = mpc_launch_fpc(d_lines, n, h->L, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
   } else if (h->algorithm == 1) {
     e = mpc_launch_bdi(d_lines, n, h->L, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
@@ -317,6 +320,17 @@ int sync_all(mpc_handle *h)
 // raw device statistics -> ABI vector (added into `vec`)
 void derive_stats(const mpc_handle *h, const std::vector<u64> &raw, std::vector<u64> &vec)
 {
+  if (h->algorithm == 3) {
+    // lines are not recoverable from the pattern counts: the kernel counts compressed bits per line,
+    // and every line contributes exactly 33 planes = TotalWords / 33
+    const u64 lines = raw[7] / 33ull;
+    vec[0] += lines;
+    vec[1] += lines * 8ull * (u64)h->L;
+    vec[2] += raw[8];
+    vec[3] += raw[7];
+    for (int i = 0; i < 7; i++) vec[4 + i] += raw[i];
+    return;
+  }
   if (h->algorithm == 2) {
     u64 words = 0;
     for (int i = 0; i < 8; i++) {
@@ -465,6 +479,30 @@ int mpc_create_bdi(unsigned line_size, int device, mpc_handle **out)
   return MPC_OK;
 }
 
+int mpc_create_bpc(unsigned line_size, int device, mpc_handle **out)
+{
+  if (!out) return MPC_E_INVAL;
+  *out = nullptr;
+  if (!(line_size == 32 || line_size == 64 || line_size == 128)) {
+    g_create_error = "BPC line size must be 32, 64 or 128 bytes";
+    return MPC_E_INVAL;
+  }
+  mpc_handle *h = new (std::nothrow) mpc_handle();
+  if (!h) return MPC_E_NOMEM;
+  h->algorithm = 3;
+  h->L = (int)line_size;
+  h->raw_len = MPC_BPC_RAW_LEN;
+  h->stats_len = 11;
+  int rc = pick_device(device, &h->device, &h->num_cus);
+  if (rc == MPC_OK) rc = finish_create(h);
+  if (rc != MPC_OK) {
+    mpc_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return MPC_OK;
+}
+
 int mpc_create_fpc(unsigned line_size, int device, mpc_handle **out)
 {
   if (!out) return MPC_E_INVAL;
@@ -522,9 +560,9 @@ int mpc_get_info(const mpc_handle *h, mpc_info *info)
   info->algorithm = h->algorithm;
   info->line_size = h->L;
   info->num_modules = h->algorithm == 0 ? h->cfg.M : 0;
-  info->num_clusters = h->algorithm == 0 ? h->cfg.M + 1 : (h->algorithm == 1 ? 9 : 8);
+  info->num_clusters = h->algorithm == 0 ? h->cfg.M + 1 : (h->algorithm == 1 ? 9 : (h->algorithm == 2 ? 8 : 7));
   info->hist_bins = h->algorithm == 0 ? h->cfg.hist_bins : 0;
-  info->kernel_path = h->algorithm == 2 ? MPC_PATH_FPC
+  info->kernel_path = h->algorithm == 3 ? MPC_PATH_BPC : h->algorithm == 2 ? MPC_PATH_FPC
                       : h->algorithm == 1 ? MPC_PATH_BDI : (h->plan.fast ? MPC_PATH_VPC_FAST : MPC_PATH_VPC_GENERIC);
   info->device = h->device;
   info->stats_len = h->stats_len;

@@ -67,3 +67,5 @@ static inline uint64_t mpc_vpc_raw_len(int K, int bins) { return 2ull * (uint64_
 #define MPC_BDI_RAW_LEN 10
 /*   FPC: [0,8) Counts (Prefix0..7)  [8] compressed_bits                        */
 #define MPC_FPC_RAW_LEN 9
+/*   BPC: [0,7) Counts (BPCPattern order)  [7] TotalWords  [8] compressed_bits  */
+#define MPC_BPC_RAW_LEN 9

@@ -4,6 +4,7 @@
 //   vpc_generic_kernel     VPC, any configuration the reference can run
 //   bdi_kernel             BDI baseline (reference src/compressor/BDI.cpp)
 //   fpc_kernel             FPC baseline (reference src/compressor/FPC.cpp)
+//   bpc_kernel             BPC baseline (reference src/compressor/BPC.cpp)
 //   synth_kernel / read_probe_kernel   measurement helpers
 #include "mpc_kernel_common.h"
 
@@ -489,6 +490,125 @@ fpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// BPC (reference BPC.cpp:20-185): deltas of consecutive 32-bit words (33-bit two's
+// complement: the words are zero-extended, see DESIGN.md "Deliberate deviations"), the 33
+// delta bit planes DBP[c] (bit r = bit c of delta r), DBX[c] = DBP[c] ^ DBP[c+1], coded from
+// plane 32 down: zero-DBX runs (3 bits for one plane, 7 for 2..33), zero DBP 5, all ones
+// (0x7fffffff, i.e. only with 31 deltas) 5, one 1 / two adjacent 1s 10, anything else 32
+// bits; the first word always costs 3 + 4 bits (BPC.cpp:96-108 assigns in its first test).
+// One lane per line: the R x 32 bit matrix of the delta words (R = 8, 16, 32 rows incl. one
+// zero row) is transposed with a butterfly network of masked swaps, then the planes are
+// walked in registers.
+// ---------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void bit_transpose_blocks(u32 (&A)[R])     // R x R blocks side by side, LSB indexing
+{
+  constexpr int STAGES = R == 32 ? 5 : (R == 16 ? 4 : 3);
+#pragma unroll
+  for (int st = 0; st < STAGES; st++) {
+    const int j = (R / 2) >> st;
+    const u32 m = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      if (k & j) continue;
+      const u32 t = ((A[k] >> j) ^ A[k + j]) & m;
+      A[k + j] ^= t;
+      A[k] ^= t << j;
+    }
+  }
+}
+
+template <int NW>   // words per line: 8, 16 or 32
+__global__ void __launch_bounds__(256)
+bpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ sizes_out,
+           int8_t *__restrict__ sel_out, u64 *gstats)
+{
+  __shared__ u64 s_counts[MPC_BPC_RAW_LEN];
+  if (threadIdx.x < MPC_BPC_RAW_LEN) s_counts[threadIdx.x] = 0;
+  __syncthreads();
+  constexpr int ND = NW - 1;                           // deltas = rows of the bit matrix (row NW-1 is zero)
+  u64 even = 0, odd = 0;                               // pattern counts 0,2,4,6 / 1,3,5 in 16-bit fields
+  u64 words_acc = 0, bits_acc = 0;
+  u32 since_flush = 0;
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u64 e = (even >> (16 * k)) & 0xffffull, o = (odd >> (16 * k)) & 0xffffull;
+      if (e) atomicAdd(&s_counts[2 * k], e);
+      if (o && k < 3) atomicAdd(&s_counts[2 * k + 1], o);
+    }
+    if (words_acc) atomicAdd(&s_counts[7], words_acc);
+    if (bits_acc) atomicAdd(&s_counts[8], bits_acc);
+    even = odd = words_acc = bits_acc = 0;
+  };
+  for (u64 line = (u64)blockIdx.x * blockDim.x + threadIdx.x; line < n_lines; line += (u64)gridDim.x * blockDim.x) {
+    u32 w[NW];
+    const uint4 *src = lines + line * (NW / 4);
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) {
+      const uint4 q = src[i];
+      w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+    }
+    // deltas: low 32 bits in A[r], bit 32 (the borrow) collected into plane 32
+    u32 A[NW], top = 0;
+#pragma unroll
+    for (int r = 0; r < ND; r++) {
+      A[r] = w[r + 1] - w[r];
+      top |= (w[r + 1] < w[r] ? 1u : 0u) << r;
+    }
+    A[ND] = 0;
+    bit_transpose_blocks<NW>(A);
+    // plane c: bits (c % NW) of block c / NW
+    u32 length = 3 + 4, run = 0, total_words = 0;
+    u64 pc = 0;                        // this line's pattern counts, 8-bit fields
+    u32 above = 0;                     // DBP of the plane above
+#pragma unroll
+    for (int c = 32; c >= 0; c--) {
+      u32 dbp;
+      if (c == 32) dbp = top;
+      else if constexpr (NW == 32) dbp = A[c];
+      else dbp = (A[c % NW] >> (NW * (c / NW))) & ((1u << NW) - 1u);
+      const u32 dbx = c == 32 ? dbp : (dbp ^ above);
+      above = dbp;
+      const bool nz = dbx != 0u;
+      // a non-zero plane closes the zero run before it
+      const u32 zrl = run == 0u ? 0u : (run == 1u ? 3u : 7u);
+      const u32 ones = (u32)__popc(dbx);
+      const bool allones = ND == 31 && dbx == 0x7fffffffu;
+      const bool two = ones == 2u && (dbx & (dbx >> 1)) != 0u;
+      const u32 pat = dbp == 0u ? 2u : allones ? 6u : ones == 1u ? 3u : two ? 4u : 0u;
+      const u32 cost = (dbp == 0u || allones) ? 5u : (ones == 1u || two) ? 10u : 32u;
+      if (nz) {
+        length += zrl + cost;
+        total_words += run + 1u;
+        pc += (1ull << (8u * pat)) + (run ? (1ull << 8) : 0ull);
+        run = 0;
+      } else {
+        run++;
+      }
+    }
+    if (run) {
+      length += run == 1u ? 3u : 7u;
+      total_words += run;
+      pc += 1ull << 8;
+    }
+    even += pc & 0x00ff00ff00ff00ffull;
+    odd += (pc >> 8) & 0x00ff00ff00ff00ffull;
+    words_acc += total_words;
+    bits_acc += length;
+    if (sizes_out) sizes_out[line] = (uint16_t)length;
+    if (sel_out) sel_out[line] = 0;
+    if (++since_flush == 1023u) {      // 1023 lines x 34 counts < 2^16 per field
+      flush();
+      since_flush = 0;
+    }
+  }
+  flush();
+  __syncthreads();
+  if (threadIdx.x < MPC_BPC_RAW_LEN && s_counts[threadIdx.x]) atomicAdd(&gstats[threadIdx.x], s_counts[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
 // measurement helpers
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ u64 splitmix64(u64 x)
@@ -570,6 +690,19 @@ extern "C" hipError_t mpc_launch_fpc(const void *d_lines, u64 n_lines, int L, ui
   case 32: hipLaunchKernelGGL(fpc_kernel<8>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   case 64: hipLaunchKernelGGL(fpc_kernel<16>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   case 128: hipLaunchKernelGGL(fpc_kernel<32>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
+  default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mpc_launch_bpc(const void *d_lines, u64 n_lines, int L, uint16_t *d_sizes, int8_t *d_sel,
+                                     u64 *d_stats, int grid, hipStream_t stream)
+{
+  const uint4 *l = static_cast<const uint4 *>(d_lines);
+  switch (L) {
+  case 32: hipLaunchKernelGGL(bpc_kernel<8>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
+  case 64: hipLaunchKernelGGL(bpc_kernel<16>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
+  case 128: hipLaunchKernelGGL(bpc_kernel<32>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -1,7 +1,7 @@
 // main.cpp -- the `compressor` command line of the reference (src/main.cpp), kept
 // flag-for-flag:  compressor -a ALGO -i TRACE [-c CONFIG.json] [-o OUTDIR] [-h]
 // stdout "comp.ratio: <double>", CSV rows appended to OUTDIR/<stem>_results.csv and
-// OUTDIR/<stem>_results_detail.csv.  This build evaluates VPC, BDI and FPC (the hot path
+// OUTDIR/<stem>_results_detail.csv.  This build evaluates VPC, BDI, FPC and BPC (the hot path
 // of SURVEY.md section 8) on the MI355X; traces are .npy files or GPGPU-Sim .log
 // files (GLOBAL_ACC_R / GLOBAL_ACC_W requests, reference main.cpp:222-224).  The other
 // algorithm names and the APSim .txt format are recognised and reported as not part
@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "BDI.h"
+#include "BPC.h"
 #include "FPC.h"
 #include "LoaderGPGPU.h"
 #include "LoaderNPY.h"
@@ -111,9 +112,10 @@ int main(int argc, char **argv)
     compressor = new comp::BDI(lineSize);
   } else if (algorithm == "FPC") {
     compressor = new comp::FPC(lineSize);
-  } else if (algorithm == "BPC" || algorithm == "CPACK" || algorithm == "SC2" ||
-             algorithm == "PATTERN" || algorithm == "VIEWER") {
-    std::cout << "Algorithm " << algorithm << " is not part of this build: VPC, BDI and FPC are (see DESIGN.md, \"Out of scope\")."
+  } else if (algorithm == "BPC") {
+    compressor = new comp::BPC(lineSize);
+  } else if (algorithm == "CPACK" || algorithm == "SC2" || algorithm == "PATTERN" || algorithm == "VIEWER") {
+    std::cout << "Algorithm " << algorithm << " is not part of this build: VPC, BDI, FPC and BPC are (see DESIGN.md, \"Out of scope\")."
               << std::endl;
     return 1;
   } else {

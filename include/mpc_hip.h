@@ -45,13 +45,14 @@ typedef struct mpc_handle mpc_handle;
 #define MPC_PATH_VPC_GENERIC  2  /* any table / root / scan order              */
 #define MPC_PATH_BDI          3
 #define MPC_PATH_FPC          4
+#define MPC_PATH_BPC          5
 
 typedef struct {
   int32_t abi_version;
-  int32_t algorithm;        /* 0 = VPC, 1 = BDI, 2 = FPC */
+  int32_t algorithm;        /* 0 = VPC, 1 = BDI, 2 = FPC, 3 = BPC */
   int32_t line_size;        /* bytes per line (L) */
   int32_t num_modules;      /* VPC: M; BDI: 0 */
-  int32_t num_clusters;     /* VPC: M+1 (cluster -1 .. M-1); BDI: 9 states; FPC: 8 prefixes */
+  int32_t num_clusters;     /* VPC: M+1 (cluster -1 .. M-1); BDI: 9 states; FPC: 8 prefixes; BPC: 7 patterns */
   int32_t hist_bins;        /* VPC: bins per cluster in the stats vector */
   int32_t kernel_path;      /* MPC_PATH_* */
   int32_t device;           /* HIP device ordinal the handle is bound to */
@@ -70,6 +71,12 @@ int mpc_create_bdi(unsigned line_size, int device, mpc_handle **out);
  * One definition where the reference has undefined behaviour: a zero run ends at the end of
  * the line (FPC.cpp:26 reads past it).  Parity is unpinned (no fixture).     */
 int mpc_create_fpc(unsigned line_size, int device, mpc_handle **out);
+/* `new comp::BPC(lineSize)` (BPC.h:93-99): bit-plane compression (BPC.cpp:20-185).  Per-line
+ * output: size in bits (may exceed 8*L: the reference does not cap it); `selected` is 0.
+ * Kept as in the source: the first word always costs 3+4 bits (`if (base = 0)`,
+ * BPC.cpp:98).  Defined where the source is undefined: words are zero-extended to 64 bits
+ * (BPC.cpp:42-44 copies 4 bytes into an uninitialised int64_t).  Parity is unpinned.       */
+int mpc_create_bpc(unsigned line_size, int device, mpc_handle **out);
 void mpc_destroy(mpc_handle *h);
 
 int mpc_get_info(const mpc_handle *h, mpc_info *info);
@@ -109,6 +116,8 @@ int mpc_sync(mpc_handle *h);
  * BDI layout: [0] lines [1] original_bits [2] compressed_bits [3..11] Counts.
  * FPC layout: [0] lines [1] original_bits (32 per word) [2] compressed_bits [3..10] Counts of
  *             Prefix0..7 (FPC.h:13-23); TotalWords = their sum.
+ * BPC layout: [0] lines [1] original_bits [2] compressed_bits [3] TotalWords [4..10] Counts in
+ *             BPCPattern order (BPC.h:12-21).
  */
 int mpc_stats_len(const mpc_handle *h, uint64_t *len);
 int mpc_stats_get(mpc_handle *h, uint64_t *vec, size_t n);      /* syncs */
@@ -117,7 +126,8 @@ int mpc_stats_set(mpc_handle *h, const uint64_t *vec, size_t n);   /* = (after a
 
 /* Device-side exchange (multi-GPU without a host round trip).  The handle's device
  * accumulators ("raw" statistics: VPC [sum_r(K)] [sum_r2(K)] [histogram(K x B)], BDI
- * [Counts(9)] [compressed_bits], FPC [Counts(8)] [compressed_bits]) are plain uint64 sums, so ranks may all-reduce them
+ * [Counts(9)] [compressed_bits], FPC [Counts(8)] [compressed_bits], BPC [Counts(7)] [TotalWords] [compressed_bits]) are plain
+ * uint64 sums, so ranks may all-reduce them
  * directly: mpc_stats_copy_raw_device enqueues an asynchronous device-to-device copy of
  * the raw_len words into d_dst on hip_stream (after everything already enqueued there),
  * and mpc_stats_from_raw turns such an array -- on the host, e.g. after the all-reduce --

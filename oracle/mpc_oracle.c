@@ -515,3 +515,86 @@ void mpc_o_fpc_batch(const uint8_t *lines, int L, uint64_t n, uint16_t *sizes, m
   }
 }
 
+/* ---------------------------------------------------------------------------
+ * BPC (reference src/compressor/BPC.cpp:20-185, BPC.h:12-33)
+ * ------------------------------------------------------------------------- */
+static void bpc_pattern(mpc_o_bpc_stats *st, unsigned num_words, int selected)
+{
+  if (!st) return;
+  st->total_words += num_words;      /* BPC.h:29-33 */
+  st->counts[selected]++;
+}
+
+unsigned mpc_o_bpc_line(const uint8_t *line, int L, mpc_o_bpc_stats *st)
+{
+  static const unsigned kZrl[34] = {0, 3, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7,
+                                    7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7};   /* BPC.cpp:7 */
+  const int n = L / 4;
+  int64_t data[MPC_O_MAX_LINE / 4], deltas[MPC_O_MAX_LINE / 4];
+  for (int i = 0; i < n; i++)      /* zero-extended words (see mpc_oracle.h) */
+    data[i] = (int64_t)((uint32_t)line[4 * i] | ((uint32_t)line[4 * i + 1] << 8) | ((uint32_t)line[4 * i + 2] << 16) |
+                        ((uint32_t)line[4 * i + 3] << 24));
+  const int nd = n - 1;
+  for (int r = 1; r < n; r++) deltas[r - 1] = data[r] - data[r - 1];
+  int32_t DBP[33], DBX[33], prev = 0;
+  for (int col = 32; col >= 0; col--) {
+    int32_t buf = 0;
+    for (int row = nd - 1; row >= 0; row--) buf = (int32_t)(((uint32_t)buf << 1) | (uint32_t)((deltas[row] >> col) & 1));
+    DBP[col] = buf;
+    DBX[col] = col == 32 ? buf : (buf ^ prev);
+    prev = buf;
+  }
+  unsigned length = 3 + 4;                 /* encodeFirst: always the 4-bit sign-extended case */
+  unsigned run = 0;
+  for (int i = 32; i >= 0; i--) {
+    if (DBX[i] == 0) {
+      run++;
+      continue;
+    }
+    if (run > 0) {
+      length += kZrl[run];
+      bpc_pattern(st, run, 1);             /* ZRLE */
+    }
+    run = 0;
+    if (DBP[i] == 0) {
+      length += 5;
+      bpc_pattern(st, 1, 2);               /* Zero */
+    } else if (DBX[i] == 0x7fffffff) {
+      length += 5;
+      bpc_pattern(st, 1, 6);               /* AllOnes */
+    } else {
+      const uint32_t x = (uint32_t)DBX[i];
+      const int ones = __builtin_popcount(x);
+      if (ones == 1) {
+        length += 10;
+        bpc_pattern(st, 1, 3);             /* SingleOne */
+      } else if (ones == 2 && (x & (x >> 1)) != 0) {
+        length += 10;
+        bpc_pattern(st, 1, 4);             /* ConsecTwoOnes */
+      } else {
+        length += 32;
+        bpc_pattern(st, 1, 0);             /* Uncomp */
+      }
+    }
+  }
+  if (run > 0) {
+    length += kZrl[run];
+    bpc_pattern(st, run, 1);
+  }
+  if (st) {
+    st->lines++;
+    st->original_bits += 8ull * (uint64_t)L;
+    st->compressed_bits += length;
+    st->comp_ratio = (double)st->original_bits / (double)st->compressed_bits;
+  }
+  return length;
+}
+
+void mpc_o_bpc_batch(const uint8_t *lines, int L, uint64_t n, uint16_t *sizes, mpc_o_bpc_stats *st)
+{
+  for (uint64_t i = 0; i < n; i++) {
+    const unsigned s = mpc_o_bpc_line(lines + i * (uint64_t)L, L, st);
+    if (sizes) sizes[i] = (uint16_t)s;
+  }
+}
+

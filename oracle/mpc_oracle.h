@@ -149,6 +149,27 @@ typedef struct {
   uint64_t counts[8];         /* FPCState Prefix0..7 */
 } mpc_o_fpc_stats;
 unsigned mpc_o_fpc_line(const uint8_t *line, int L, mpc_o_fpc_stats *st);
+
+/* BPC::CompressLine (BPC.cpp:20-185), bit-plane compression: deltas of consecutive 32-bit
+ * words, 33 delta bit planes (DBP), each XORed with the plane above (DBX), run-length /
+ * pattern coded.  PARITY UNPINNED like FPC (no fixture; BPC.cpp needs the un-vendored
+ * strutil.h to compile).  Two properties of the source are kept as they are:
+ *   - encodeFirst (BPC.cpp:96-108) tests `if (base = 0)`, an assignment, so it always
+ *     returns 3 + 4 = 7 bits;
+ *   - pattern ZeroDBP (5) is never counted, a zero DBP is counted as Zero (2).
+ * One definition where the source has undefined behaviour: a word is copied into the low
+ * 4 bytes of an uninitialised int64_t (BPC.cpp:42-44); here the upper half is zero (the word
+ * is zero-extended), which makes every delta a 33-bit two's complement number.          */
+typedef struct {
+  uint64_t lines;
+  uint64_t original_bits;
+  uint64_t compressed_bits;
+  double   comp_ratio;
+  uint64_t total_words;       /* BPCResult::TotalWords: sum of UpdatePattern's numWords */
+  uint64_t counts[7];         /* BPCPattern order */
+} mpc_o_bpc_stats;
+unsigned mpc_o_bpc_line(const uint8_t *line, int L, mpc_o_bpc_stats *st);
+void mpc_o_bpc_batch(const uint8_t *lines, int L, uint64_t n, uint16_t *sizes, mpc_o_bpc_stats *st);
 void mpc_o_fpc_batch(const uint8_t *lines, int L, uint64_t n, uint16_t *sizes, mpc_o_fpc_stats *st);
 
 #ifdef __cplusplus

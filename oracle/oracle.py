@@ -78,6 +78,13 @@ class OFpcStats(C.Structure):
     ]
 
 
+class OBpcStats(C.Structure):
+    _fields_ = [
+        ("lines", C.c_uint64), ("original_bits", C.c_uint64), ("compressed_bits", C.c_uint64),
+        ("comp_ratio", C.c_double), ("total_words", C.c_uint64), ("counts", C.c_uint64 * 7),
+    ]
+
+
 def build(ref: bool = True) -> None:
     """Compile the oracle (and oracle/_ref when /root/reference is mounted)."""
     subprocess.run(["make", "-s", "-C", HERE, "all"], check=True)
@@ -114,6 +121,8 @@ def lib() -> C.CDLL:
         L.mpc_o_bdi_batch.restype = None
         L.mpc_o_fpc_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(OFpcStats)]
         L.mpc_o_fpc_batch.restype = None
+        L.mpc_o_bpc_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(OBpcStats)]
+        L.mpc_o_bpc_batch.restype = None
         L.mpc_o_bdi_reduce_sign.argtypes = [C.c_uint64]
         L.mpc_o_bdi_reduce_sign.restype = C.c_uint64
         L.mpc_o_bdi_check.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint]
@@ -295,4 +304,29 @@ class FpcOracle:
     def stats_vector(self) -> np.ndarray:
         return np.array([self.st.lines, self.st.original_bits, self.st.compressed_bits]
                         + [self.st.counts[i] for i in range(8)], dtype=np.uint64)
+
+
+class BpcOracle:
+    """BPC::CompressLine restatement (reference BPC.cpp:20-185) -- PARITY UNPINNED, see mpc_oracle.h."""
+
+    def __init__(self, line_size: int):
+        if line_size % 4 or line_size < 8 or line_size > 128:
+            raise ValueError("BPC needs 8..128-byte lines, a multiple of 4")
+        self.L = line_size
+        self.reset()
+
+    def reset(self) -> None:
+        self.st = OBpcStats()
+
+    def compress(self, lines: np.ndarray, stats: bool = True) -> np.ndarray:
+        lines = np.ascontiguousarray(lines, dtype=np.uint8)
+        assert lines.ndim == 2 and lines.shape[1] == self.L
+        n = lines.shape[0]
+        sizes = np.zeros(n, dtype=np.uint16)
+        lib().mpc_o_bpc_batch(lines.ctypes.data, self.L, n, sizes.ctypes.data, C.byref(self.st) if stats else None)
+        return sizes
+
+    def stats_vector(self) -> np.ndarray:
+        return np.array([self.st.lines, self.st.original_bits, self.st.compressed_bits, self.st.total_words]
+                        + [self.st.counts[i] for i in range(7)], dtype=np.uint64)
 

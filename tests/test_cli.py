@@ -60,7 +60,7 @@ def test_out_of_scope_algorithms_and_formats(cli, traces, tmp_path):
     d = tmp_path / "ds"
     d.mkdir()
     p = traces.save_npy(str(d / "t.npy"), traces.zeros(8, 64))
-    for algo in ("BPC", "CPACK", "SC2", "PATTERN", "VIEWER"):
+    for algo in ("CPACK", "SC2", "PATTERN", "VIEWER"):
         r = run([cli, "-a", algo, "-i", p, "-o", str(tmp_path)])
         assert r.returncode == 1 and "not part of this build" in r.stdout
     r = run([cli, "-a", "BDI", "-i", str(d / "t.txt"), "-o", str(tmp_path)])
@@ -240,6 +240,24 @@ def test_cli_fpc(cli, oracle, traces, tmp_path):
         "".join(f"{o.st.counts[i]}," for i in range(8)) + "\n"
     assert (tmp_path / "FPC_results.csv").read_text() == hdr + row
     assert not (tmp_path / "FPC_results_detail.csv").exists()
+
+
+@pytest.mark.gpu
+def test_cli_bpc(cli, oracle, traces, tmp_path):
+    ds = tmp_path / "bench"
+    ds.mkdir()
+    data = np.concatenate([traces.structured(3000, 128), traces.counters_u32(1000, 128), traces.zeros(40, 128)])
+    p = traces.save_npy(str(ds / "app.npy"), data)
+    r = run([cli, "-a", "BPC", "-i", p, "-o", str(tmp_path)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    o = oracle.BpcOracle(128)
+    o.compress(data[:-1])
+    assert r.stdout.strip().split("\n")[-1] == "comp.ratio: " + fmt_double(o.st.comp_ratio)
+    hdr = ("Workload,Original Size,Compressed Size,Compression Ratio,Total Words,Pattern0,Pattern1,Pattern2,Pattern3,"
+           "Pattern4,Pattern5,Pattern6,\n")
+    row = f"bench_app,{o.st.original_bits},{o.st.compressed_bits},{fmt_double(o.st.comp_ratio)},{o.st.total_words}," + \
+        "".join(f"{o.st.counts[i]}," for i in range(7)) + "\n"
+    assert (tmp_path / "BPC_results.csv").read_text() == hdr + row
 
 
 @pytest.mark.gpu

@@ -275,6 +275,35 @@ def test_fpc(mpc, oracle, traces, L):
     assert ev.result()["comp_ratio"] == o.st.comp_ratio and ev.result()["total_words"] == o.st.total_words
 
 
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_bpc(mpc, oracle, traces, L):
+    """BPC baseline against the oracle's source-reading restatement (parity unpinned): ramps and
+    constant lines (zero runs, all-ones planes), sparse deltas (single / adjacent ones), wrap-around
+    deltas (borrow plane), random and structured data."""
+    rng = np.random.default_rng(L + 1)
+    n, W = 6000, L // 4
+    base = rng.integers(0, 1 << 32, (n, 1), dtype=np.uint64)
+    step = rng.choice(np.array([0, 1, 2, 3, 255, 256, 0xFFFFFFFF, 0xFFFFFF00, 65536, 0x80000000], dtype=np.uint64), (n, 1))
+    words = (base + step * np.arange(W, dtype=np.uint64)[None, :]) & np.uint64(0xFFFFFFFF)
+    bump = rng.random((n, W)) < 0.08                              # sparse extra deltas
+    words = (words + bump * rng.integers(1, 4, (n, W)).astype(np.uint64)) & np.uint64(0xFFFFFFFF)
+    words[::9] = np.uint64(0)
+    words[1::9, :] = words[1::9, :1]
+    lines = np.concatenate([words.astype("<u4").view(np.uint8).reshape(n, L), traces.structured(3000, L),
+                            traces.mixed(1000, L), traces.random_u32(500, L), traces.counters_u32(500, L),
+                            traces.pointers_u64(500, L)])
+    ev, o = mpc.BPC(L), oracle.BpcOracle(L)
+    assert ev.kernel_path == mpc.MPC_PATH_BPC
+    s_ref = o.compress(lines)
+    s, sel = ev.compress_lines(lines)
+    bad = np.nonzero(s != s_ref)[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}: {s[bad[:5]]} vs {s_ref[bad[:5]]}"
+    assert (ev.stats_vector() == o.stats_vector()).all()
+    counts = o.stats_vector()[4:]
+    assert counts[5] == 0 and (np.delete(counts, [5] + ([] if L == 128 else [6])) > 0).all()   # ZeroDBP is never used
+    assert ev.result()["comp_ratio"] == o.st.comp_ratio and ev.result()["total_words"] == 33 * len(lines)
+
+
 def test_edge_cases(mpc, oracle, configs, traces):
     cfg = configs.probe_config(64)
     ev = mpc.VPC(cfg)

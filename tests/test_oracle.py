@@ -241,3 +241,28 @@ def test_kat_fpc_by_hand(oracle):
     assert size([1] + [0] * 15) == 7 + 6                 # a run that reaches the end of the line
     assert o.st.total_words == 13 * 16 and sum(o.st.counts) == 13 * 16
 
+
+def test_kat_bpc_by_hand(oracle):
+    """BPC sizes worked out by hand from BPC.cpp:20-185: first word always 3+4 bits; 33 delta bit
+    planes, zero-DBX runs 3 / 7 bits, zero DBP or all-ones (31 deltas only) 5, one 1 or two adjacent
+    1s 10, else 32.  No reference fixture exists for BPC: source reading only."""
+    def size(L, words):
+        o = oracle.BpcOracle(L)
+        return int(o.compress(np.array(words, dtype="<u4").view(np.uint8).reshape(1, -1))[0]), o
+    for L in (32, 64, 128):
+        n = L // 4
+        assert size(L, [0] * n)[0] == 7 + 7                       # one run of 33 zero planes
+        assert size(L, [0xDEADBEEF] * n)[0] == 7 + 7              # all deltas zero
+        s, o = size(L, list(range(n)))                            # delta +1: plane 0 all ones, planes 32..1 zero
+        assert s == 7 + 7 + (5 if L == 128 else 32) and o.st.total_words == 33
+        s, o = size(L, list(range(n, 0, -1)))                     # delta -1: every plane all ones, DBX only on plane 32
+        assert s == 7 + (5 if L == 128 else 32) + 7
+        s, o = size(L, [0] * (n - 1) + [1])                       # one delta of +1 in the last row: single one on plane 0
+        assert s == 7 + 7 + 10 and list(o.st.counts) == [0, 1, 0, 1, 0, 0, 0]
+        s, o = size(L, [0] * (n - 2) + [1, 2])                    # two adjacent ones on plane 0
+        assert s == 7 + 7 + 10 and list(o.st.counts) == [0, 1, 0, 0, 1, 0, 0]
+        s, o = size(L, [0, 2] + [2] * (n - 2))                    # a single +2: single one on plane 1, then plane 0: DBP 0 -> "Zero"
+        assert s == 7 + 7 + 10 + 5 and list(o.st.counts) == [0, 1, 1, 1, 0, 0, 0]
+    rnd = np.random.default_rng(1).integers(0, 256, (1, 64), dtype=np.uint8)
+    assert int(oracle.BpcOracle(64).compress(rnd)[0]) == 7 + 33 * 32      # nothing compresses: larger than the line
+

@@ -10,7 +10,7 @@ n = (16 << 30) // L
 buf = torch.empty(n * L, dtype=torch.uint8, device="cuda:0")
 mpc.synth_fill(buf.data_ptr(), n, L, wl)
 torch.cuda.synchronize()
-ev = mpc.VPC(cfgs.probe_config(L)) if algo == "VPC" else (mpc.BDI(L) if algo == "BDI" else mpc.FPC(L))
+ev = mpc.VPC(cfgs.probe_config(L)) if algo == "VPC" else {"BDI": mpc.BDI, "FPC": mpc.FPC, "BPC": mpc.BPC}[algo](L)
 st = torch.cuda.Stream()
 for _ in range(2):
     ev.compress_device(buf.data_ptr(), n, stream=st.cuda_stream)
