@@ -69,7 +69,7 @@ __device__ __forceinline__ u32 shuffled_word(const u32 (&x)[W], int j)
   return plane_bytes<W>(x, j % NG, 3 - j / NG);
 }
 
-// predicted word from the base bytes b (see window_predict in mpc_kernel_common.h)
+// predicted word from the base bytes b: b + diff constant, or b shifted / masked per weight class
 template <int KIND>
 __device__ __forceinline__ u32 window_predict(u32 b, u32 c1, u32 c2, const MpcFastModule &fm)
 {
