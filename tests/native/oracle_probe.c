@@ -44,6 +44,10 @@ int main(void)
     st.hist = calloc((size_t)(MPC_O_MAX_MODULES + 1) * st.hist_bins, sizeof(uint64_t));
     mpc_o_bdi_stats bst;
     memset(&bst, 0, sizeof(bst));
+    mpc_o_fpc_stats fst;
+    memset(&fst, 0, sizeof(fst));
+    mpc_o_bpc_stats pst;
+    memset(&pst, 0, sizeof(pst));
     uint8_t line[MPC_O_MAX_LINE];
     for (int i = 0; i < 3000; i++) {
       int mode = i % 5;
@@ -53,7 +57,10 @@ int main(void)
       int sel;
       total += mpc_o_vpc_line(&cfg, line, &sel, &st);
       total += mpc_o_bdi_line(line, L, &sel, &bst);
+      total += mpc_o_fpc_line(line, L, &fst);
+      total += mpc_o_bpc_line(line, L, &pst);
     }
+    if (fst.total_words != 3000ull * (unsigned)(L / 4) || pst.total_words != 3000ull * 33ull) { printf("word counts\n"); return 1; }
     free(st.hist);
   }
   printf("ok %llu\n", total);
