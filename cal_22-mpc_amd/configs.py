@@ -100,6 +100,25 @@ def probe_config(line_size: int = 64, encoding_bits: Optional[List[int]] = None)
     return make_config(L, mods, encoding_bits)
 
 
+def probe_config_u64(line_size: int = 64, encoding_bits: Optional[List[int]] = None) -> Dict:
+    """The probe configuration for 8-byte elements (pointers, int64, fp64): the DiffBase /
+    WeightBase predictors look two words back (BaseIndexTable[i] = max(i-8, 0)); diff 1 on the
+    least significant byte of every element, weights 1 / 0.5 on even / odd bytes."""
+    L = line_size
+    base = [max(i - 8, 0) for i in range(L)]
+    diff = [1 if i % 8 == 0 else 0 for i in range(L)]
+    weight = [1.0 if i % 2 == 0 else 0.5 for i in range(L)]
+    mods = [
+        {"name": "AllZero"},
+        {"name": "AllWordSame"},
+        one_base(L, 0, True),
+        consecutive_base(L, 0, True),
+        diff_base(L, base, diff, 0, False),
+        weight_base(L, base, weight, 0, True),
+    ]
+    return make_config(L, mods, encoding_bits)
+
+
 def write_config(cfg: Dict, path: str) -> str:
     with open(path, "w") as f:
         json.dump(cfg, f)

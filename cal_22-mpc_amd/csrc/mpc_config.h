@@ -261,15 +261,21 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     f.tab_off = (int32_t)plan.tab.size();
     if (m.pred_kind == PRED_ONEBASE) { f.kind = MPC_FK_ONEBASE; continue; }
     if (m.pred_kind == PRED_CONSEC) { f.kind = MPC_FK_CONSEC; continue; }
-    // windowed tables: every base byte lies in the own or the previous dword
+    // windowed tables: every base byte lies in the own or the previous dword -- or, for 8-byte
+    // elements, every byte from word 2 on is predicted by the same byte two words back
+    // (BaseIndexTable[i] = i - 8), which the lane-per-line kernel serves straight from registers
     std::vector<uint32_t> sel((size_t)W, 0), c1((size_t)W, 0), c2((size_t)W, 0);
     int shifts[2] = {0, 0}, nshift = 0;
+    bool stride2 = L >= 16;
+    for (int i = 8; i < L; i++) stride2 = stride2 && m.base[(size_t)i] == i - 8;
     for (int i = 0; i < L && plan.fast; i++) {
       const int w = i / 4, k = i % 4;
       if (i == 0) { sel[0] |= 0x0cu; continue; }  // root: predicted byte forced to 0
       const int b = m.base[(size_t)i];
       int s;
-      if (w == 0) {
+      if (stride2 && w >= 2) {
+        s = k;                                     // the same byte of the source word (two words back)
+      } else if (w == 0) {
         if (b > 3) { no(tag + "BaseIndexTable is not windowed (own/previous dword)"); break; }
         s = 4 + b;
       } else {
@@ -325,6 +331,14 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     f.prev_word = 1;
     for (size_t w = 1; w < sel.size(); w++)
       if (sel[w] != 0x03020100u || c1[w] != c1[1] || c2[w] != c2[1]) f.prev_word = 0;
+    if (stride2) {
+      // two-words-back tables must repeat with the element (2 words) from word 2 on: the kernel
+      // has no byte gather for them and reads the entries of words 2 and 3 for even / odd words
+      f.prev_word = 2;
+      for (size_t w = 4; w < sel.size(); w++)
+        if (c1[w] != c1[2 + (w & 1)] || c2[w] != c2[2 + (w & 1)]) { no(tag + "BaseIndexTable i-8 with constants that do not repeat every 8 bytes"); break; }
+      if (!plan.fast) break;
+    }
   }
   while (plan.tab.size() % 4) plan.tab.push_back(0);
   if (plan.tab.empty()) plan.tab.assign(4, 0);

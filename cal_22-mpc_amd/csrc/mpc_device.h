@@ -25,9 +25,10 @@ struct MpcFastModule {
   int32_t ls1, rs1;   /* WEIGHT: first shift class  ((b << ls1) >> rs1) & c1 */
   int32_t ls2, rs2;   /* WEIGHT: second shift class ((b << ls2) >> rs2) & c2 */
   int32_t tab_off;    /* DIFF/WEIGHT: dword offset of {sel, c1, c2, c1 & 0x7f.., c1 & 0x80..}[L/4 each] in tab */
-  int32_t prev_word;  /* DIFF/WEIGHT: every base byte of words 1.. is the same byte of the previous word
-                         (BaseIndexTable[i] = i - 4) and the table entries of words 1.. are identical:
-                         the kernel skips the v_perm_b32 and reads two table entries instead of L/4 */
+  int32_t prev_word;  /* DIFF/WEIGHT periodic tables.  1: every base byte of words 1.. is the same byte of the
+                         previous word (BaseIndexTable[i] = i - 4) and the table entries of words 1.. are
+                         identical: no v_perm_b32, two table entries instead of L/4.  2: the same two words
+                         back (i - 8, 8-byte elements) from word 2 on, entries repeating every 2 words.  0: no */
 };
 
 /* generic-path module tables: byte offsets into MpcVpcParams::gtab */

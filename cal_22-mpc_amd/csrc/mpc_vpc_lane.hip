@@ -39,7 +39,9 @@ namespace {
 // every base byte of words 1.. is the same byte of the previous word and the table entries of
 // words 1.. are identical -- no v_perm_b32, two table entries (word 0, the other words)
 constexpr int LK_PW = 8;
+constexpr int LK_PW2 = 16;    // the same two words back (prev_word == 2: BaseIndexTable[i] = i - 8)
 __device__ __host__ constexpr int lk_base(int kind) { return kind & 7; }
+__device__ __host__ constexpr int lk_dist(int kind) { return (kind & LK_PW2) ? 2 : ((kind & LK_PW) ? 1 : 0); }
 
 template <int W>
 struct Lane {
@@ -85,7 +87,8 @@ __device__ __forceinline__ u32 window_predict(u32 b, u32 c1, u32 c2, const MpcFa
 template <int W, int KIND>
 __device__ __forceinline__ u32 window_base(const Lane<W> &c, int e, const u32 *__restrict__ t)
 {
-  if ((KIND & LK_PW) && e > 0) return c.x[e - 1];
+  constexpr int D = lk_dist(KIND);
+  if (D && e >= D) return c.x[e - D];
   return perm(c.x[e], e ? c.x[e - 1] : 0u, t[e]);
 }
 
@@ -95,7 +98,8 @@ template <int W, int KIND, bool FULL = true>
 __device__ __forceinline__ u32 window_residue(const Lane<W> &c, int e, const u32 *__restrict__ t, const MpcFastModule &fm)
 {
   const u32 b = window_base<W, KIND>(c, e, t);
-  const int k = (KIND & LK_PW) ? (e ? 1 : 0) : e;     // table entry of word e
+  constexpr int D = lk_dist(KIND);
+  const int k = D == 2 ? (e < 2 ? e : 2 + (e & 1)) : (D == 1 ? (e ? 1 : 0) : e);     // table entry of word e
   if constexpr (lk_base(KIND) == MPC_FK_WEIGHT) {
     // class 1 unshifted (mask c1), class 2 shifted right (mask c2, MSBs clear): the low 7 bits
     // and the MSB of the predicted byte come from the pre-split masks t[3W..], t[4W..]
@@ -278,9 +282,18 @@ __device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcP
     switch (fm.kind) {
     case MPC_FK_ONEBASE: lane_residue<W, MPC_FK_ONEBASE>(c, fm, P.tab, r, root_r); break;
     case MPC_FK_CONSEC: lane_residue<W, MPC_FK_CONSEC>(c, fm, P.tab, r, root_r); break;
-    case MPC_FK_DIFF: lane_residue<W, MPC_FK_DIFF>(c, fm, P.tab, r, root_r); break;
-    case MPC_FK_WEIGHT: lane_residue<W, MPC_FK_WEIGHT>(c, fm, P.tab, r, root_r); break;
-    default: lane_residue<W, MPC_FK_WEIGHT2>(c, fm, P.tab, r, root_r); break;
+    case MPC_FK_DIFF:
+      if (fm.prev_word == 2) lane_residue<W, MPC_FK_DIFF | LK_PW2>(c, fm, P.tab, r, root_r);
+      else lane_residue<W, MPC_FK_DIFF>(c, fm, P.tab, r, root_r);
+      break;
+    case MPC_FK_WEIGHT:
+      if (fm.prev_word == 2) lane_residue<W, MPC_FK_WEIGHT | LK_PW2>(c, fm, P.tab, r, root_r);
+      else lane_residue<W, MPC_FK_WEIGHT>(c, fm, P.tab, r, root_r);
+      break;
+    default:
+      if (fm.prev_word == 2) lane_residue<W, MPC_FK_WEIGHT2 | LK_PW2>(c, fm, P.tab, r, root_r);
+      else lane_residue<W, MPC_FK_WEIGHT2>(c, fm, P.tab, r, root_r);
+      break;
     }
     const u32 z = lane_leading_zero_rows<W>(r);
     const bool take = best.z <= z;     // ties go to the later module (VPC.cpp:389)
@@ -693,10 +706,11 @@ bool lane_seq_matches(const MpcVpcParams *P)
   const int kinds[n > 0 ? n : 1] = {KINDS...};
   if (P->n_pred != n || n == 0) return false;
   for (int q = 0; q < n; q++) {
-    // a periodic-table instantiation (LK_PW) needs the flag; the plain one runs any table
+    // a periodic-table instantiation (LK_PW / LK_PW2) needs its flag; the plain one runs any table
+    // that has a byte gather, i.e. all but the two-words-back ones
     const MpcFastModule &f = P->fm[q];
     if (f.kind != lk_base(kinds[q])) return false;
-    if ((kinds[q] & LK_PW) && !f.prev_word) return false;
+    if (lk_dist(kinds[q]) ? f.prev_word != lk_dist(kinds[q]) : f.prev_word == 2) return false;
   }
   return true;
 }
@@ -726,7 +740,10 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
 // the module sequences this kernel is instantiated for
 #define DFP (MPC_FK_DIFF | LK_PW)
 #define WTP (MPC_FK_WEIGHT | LK_PW)
-#define MPC_LANE_SEQUENCES(X) X(OB, CS, DFP, WTP) X(OB, CS, DF, WT) X(OB, CS) X(OB) X(CS) X(DF) X(WT) X(DFP) X(WTP)
+#define DFQ (MPC_FK_DIFF | LK_PW2)
+#define WTQ (MPC_FK_WEIGHT | LK_PW2)
+#define MPC_LANE_SEQUENCES(X) \
+  X(OB, CS, DFP, WTP) X(OB, CS, DFQ, WTQ) X(OB, CS, DF, WT) X(OB, CS) X(OB) X(CS) X(DF) X(WT) X(DFP) X(WTP)
 
 }  // namespace
 

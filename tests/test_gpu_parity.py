@@ -83,6 +83,21 @@ def test_vpc_lane_kernel_sequences(mpc, oracle, configs, traces, L):
     ]
     for mods in seqs:
         _check_vpc(mpc, oracle, configs.make_config(L, mods), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+    # 8-byte elements: predictors that look two words back (BaseIndexTable[i] = i - 8) stay on the
+    # fast path; the unrolled 4-predictor sequence, and shorter ones through the run-time loop
+    lines64 = np.concatenate([lines[:4000], traces.pointers_u64(2000, L), traces.bdi_stress(1400, L)])
+    two_back = [max(i - 8, 0) for i in range(L)]
+    d8 = [(3 if i % 8 == 0 else -1 if i % 8 == 1 else 0) for i in range(L)]
+    w8 = [[1.0, 0.5, 1.0, 0.5, 1.0, 1.0, 0.5, 1.0][i % 8] for i in range(L)]
+    _check_vpc(mpc, oracle, configs.probe_config_u64(L), lines64, expect_path=mpc.MPC_PATH_VPC_FAST)
+    for mods in ([az, aws, configs.diff_base(L, two_back, d8, 0, True)],
+                 [az, configs.weight_base(L, two_back, w8, 0, False), configs.consecutive_base(L, 0, True)],
+                 [az, aws, configs.weight_base(L, two_back, [[2.0, 0.5][i % 2] for i in range(L)], 0, True),
+                  configs.diff_base(L, prev_word, diff, 0, False)]):
+        _check_vpc(mpc, oracle, configs.make_config(L, mods), lines64, expect_path=mpc.MPC_PATH_VPC_FAST)
+    # i - 8 bases whose constants do not repeat every 8 bytes have no fast form: generic kernel
+    odd = configs.make_config(L, [az, configs.diff_base(L, two_back, diff, 0, True)])
+    _check_vpc(mpc, oracle, odd, lines64[:3000], expect_path=mpc.MPC_PATH_VPC_GENERIC)
 
 
 def test_vpc_known_answers_on_gpu(mpc, configs, traces):
