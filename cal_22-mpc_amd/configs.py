@@ -119,7 +119,42 @@ def probe_config_u64(line_size: int = 64, encoding_bits: Optional[List[int]] = N
     return make_config(L, mods, encoding_bits)
 
 
+def element_config(line_size: int, element_bytes: int, encoding_bits: Optional[List[int]] = None) -> Dict:
+    """Configuration authoring helper (the reference ships no configuration files): the probe
+    module set -- AllZero, AllWordSame, OneBase, ConsecutiveBase, DiffBase, WeightBase -- with the
+    Diff / Weight predictors looking one element back, for 1-, 2-, 4- or 8-byte elements
+    (``BaseIndexTable[i] = max(i - element_bytes, 0)``, diff 1 on each element's least
+    significant byte, weight 1 / 0.5 on even / odd bytes).  Every such configuration runs on the
+    fast kernel path."""
+    if element_bytes not in (1, 2, 4, 8):
+        raise ValueError("element_bytes must be 1, 2, 4 or 8")
+    L = line_size
+    base = [max(i - element_bytes, 0) for i in range(L)]
+    diff = [1 if i % element_bytes == 0 else 0 for i in range(L)]
+    weight = [1.0 if i % 2 == 0 else 0.5 for i in range(L)]
+    mods = [{"name": "AllZero"}, {"name": "AllWordSame"}, one_base(L, 0, True), consecutive_base(L, 0, True),
+            diff_base(L, base, diff, 0, False), weight_base(L, base, weight, 0, True)]
+    return make_config(L, mods, encoding_bits)
+
+
 def write_config(cfg: Dict, path: str) -> str:
     with open(path, "w") as f:
         json.dump(cfg, f)
     return path
+
+
+if __name__ == "__main__":
+    # python cal_22-mpc_amd/configs.py --line 64 --element 8 -o cfg.json
+    import argparse
+    ap = argparse.ArgumentParser(description="write a VPC configuration for the `compressor -c` option")
+    ap.add_argument("--line", type=int, default=64, help="line size in bytes (32, 64 or 128 for the fast kernel)")
+    ap.add_argument("--element", type=int, default=4, choices=[1, 2, 4, 8], help="element size in bytes")
+    ap.add_argument("-o", "--output", default="-")
+    a = ap.parse_args()
+    text = json.dumps(element_config(a.line, a.element))
+    if a.output == "-":
+        print(text)
+    else:
+        with open(a.output, "w") as f:
+            f.write(text)
+

@@ -127,3 +127,16 @@ def test_gpgpusim_log_probe_needs_no_device(mpc, traces, tmp_path):
         mpc.gpgpusim_log_line_size(str(tmp_path / "missing.log"))
     assert e.value.code == -2
 
+
+def test_element_configs_are_fast_path(mpc, configs, oracle):
+    """The authoring helper's configurations (1/2/4/8-byte elements, every line size) parse, map to
+    the fast kernel, and equal the probe configurations where those exist."""
+    for L in (32, 64, 128):
+        for e in (1, 2, 4, 8):
+            cfg = configs.element_config(L, e)
+            d = mpc.describe_config(cfg)
+            assert d["rc"] == 0 and d["path"] == "fast", (L, e, d)
+            oracle.VpcOracle(cfg)
+        assert configs.element_config(L, 4) == configs.probe_config(L)
+        assert configs.element_config(L, 8) == configs.probe_config_u64(L)
+

@@ -152,6 +152,15 @@ def test_vpc_fast_path_variants(mpc, oracle, configs, traces):
     _check_vpc(mpc, oracle, cfg, lines)
 
 
+@pytest.mark.parametrize("element", [1, 2, 4, 8])
+def test_vpc_element_configs(mpc, oracle, configs, traces, element):
+    """The authoring helper's configurations for 1/2/4/8-byte elements, 64-byte lines."""
+    L = 64
+    lines = np.concatenate([traces.structured(3000, L, seed=element), traces.mixed(800, L), traces.pointers_u64(800, L),
+                            traces.counters_u32(500, L), traces.random_u32(300, L), traces.zeros(10, L)])
+    _check_vpc(mpc, oracle, configs.element_config(L, element), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+
+
 def _random_windowed_config(configs, rng, L):
     """Random fast-path configuration: 1..6 prediction modules of random kinds; windowed base
     tables (base byte in the own or the previous 32-bit word, never ahead of the byte), random
