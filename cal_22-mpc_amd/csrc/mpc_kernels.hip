@@ -376,10 +376,16 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
       // selected; it is skipped when that holds on every active lane of the wave
       const BdiScreen sc = bdi_screen<NW>(w);
       u32 c;
+      // a scan that succeeds costs n + 8*(B + (n-1)*D) bits whatever the immediates are (imm*D +
+      // B + (n-imm-1)*D), and a failed one more: a combination whose success cost is not below
+      // the lane's best so far cannot be selected either
 #define MPC_BDI_TRY(IDX, B, D)                                                      \
-      if (__ballot(!((sc.fails >> IDX) & 1u) || sc.floor[IDX] < best)) {            \
-        c = bdi_check<B, D, NW>(w);                                                 \
-        if (best > c) { best = c; select = IDX + 2; }                               \
+      {                                                                             \
+        constexpr u32 n_ = (NW * 4) / B, ok_cost_ = n_ + 8u * ((u32)B + (n_ - 1u) * (u32)D);   \
+        if (__ballot(ok_cost_ < best && (!((sc.fails >> IDX) & 1u) || sc.floor[IDX] < best))) {   \
+          c = bdi_check<B, D, NW>(w);                                               \
+          if (best > c) { best = c; select = IDX + 2; }                             \
+        }                                                                           \
       }
       MPC_BDI_TRY(0, 8, 1)
       MPC_BDI_TRY(1, 8, 2)
