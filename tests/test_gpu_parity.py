@@ -358,6 +358,19 @@ def test_edge_cases(mpc, oracle, configs, traces):
     # wrong line size is an error code, not a crash
     with pytest.raises(ValueError):
         ev.compress_lines(np.zeros((4, 32), dtype=np.uint8))
+    # the baselines on the same ragged sizes, statistics accumulated over the calls
+    for make, ref, two in ((mpc.BDI, oracle.BdiOracle, True), (mpc.FPC, oracle.FpcOracle, False),
+                           (mpc.BPC, oracle.BpcOracle, False)):
+        for L in (32, 128):
+            be, bo = make(L), ref(L)
+            assert be.compress_lines(np.zeros((0, L), dtype=np.uint8))[0].size == 0
+            for n in (1, 2, 63, 64, 65, 257, 1000):
+                lines = traces.structured(n, L, seed=n + L)
+                got = be.compress_lines(lines)[0]
+                want = bo.compress(lines)
+                assert (got == (want[0] if two else want)).all(), (make.__name__, L, n)
+            assert (be.stats_vector() == bo.stats_vector()).all(), (make.__name__, L)
+            be.close()
 
 
 def test_stager_multi_chunk_and_npy(mpc, oracle, configs, traces, tmp_path):
