@@ -429,11 +429,12 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ u32 fpc_prefix(u32 v)
 {
+  // width of v as a sign-extended number: nb significant bits below the sign
+  const u32 nb = 32u - (u32)__clz((int)(v ^ (u32)((int)v >> 31)));
   const u32 lo = v & 0xffffu, hi = v >> 16;
-  const bool t4 = v + 8u < 16u, t8 = v + 128u < 256u, t16 = v + 32768u < 65536u;
   const bool halves = (((lo + 128u) & 0xffffu) < 256u) && (((hi + 128u) & 0xffffu) < 256u);
   const bool rep = v == (v & 0xffu) * 0x01010101u;
-  return v == 0u ? 0u : t4 ? 1u : t8 ? 2u : t16 ? 3u : lo == 0u ? 4u : halves ? 5u : rep ? 6u : 7u;
+  return v == 0u ? 0u : nb <= 3u ? 1u : nb <= 7u ? 2u : nb <= 15u ? 3u : lo == 0u ? 4u : halves ? 5u : rep ? 6u : 7u;
 }
 
 __device__ __forceinline__ void fpc_flush(u64 &even, u64 &odd, u64 &bits, u64 *s_counts)
