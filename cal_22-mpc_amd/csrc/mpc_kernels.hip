@@ -671,6 +671,9 @@ extern "C" hipError_t mpc_launch_vpc_generic(const void *d_lines, u64 n_lines, c
                                              int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
 {
   const size_t smem = vpc_stats_smem(P->M + 1, P->hist_bins);
+  if (smem > (64u << 10))   // more than the default LDS allowance: many clusters x bins
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
   hipLaunchKernelGGL(vpc_generic_kernel, dim3(grid), dim3(128), smem, stream, static_cast<const uint8_t *>(d_lines),
                      n_lines, *P, d_sizes, d_sel, d_stats);
   return hipGetLastError();

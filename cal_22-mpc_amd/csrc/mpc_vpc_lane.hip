@@ -720,13 +720,21 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
                        int8_t *d_sel, u64 *d_stats, int grid, size_t smem, hipStream_t stream)
 {
   // OUT = per-line outputs requested (parity mode); the statistics-only build has no output code
+  // histograms of many clusters x bins need more than the 64 KiB of LDS a kernel gets by default
 #define MPC_LAUNCH(WV)                                                                                              \
-  if (d_sizes || d_sel)                                                                                            \
+  if (d_sizes || d_sel) {                                                                                          \
+    if (smem > (64u << 10))                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_lane_kernel<WV, true, KINDS...>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                            \
     hipLaunchKernelGGL((vpc_lane_kernel<WV, true, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines,     \
                        first_line, *P, d_sizes, d_sel, d_stats);                                                   \
-  else                                                                                                             \
+  } else {                                                                                                         \
+    if (smem > (64u << 10))                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_lane_kernel<WV, false, KINDS...>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                            \
     hipLaunchKernelGGL((vpc_lane_kernel<WV, false, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines,    \
-                       first_line, *P, d_sizes, d_sel, d_stats)
+                       first_line, *P, d_sizes, d_sel, d_stats);                                                   \
+  }
   switch (P->L) {
   case 32: MPC_LAUNCH(8); break;
   case 64: MPC_LAUNCH(16); break;

@@ -161,6 +161,24 @@ def test_vpc_element_configs(mpc, oracle, configs, traces, element):
     _check_vpc(mpc, oracle, configs.element_config(L, element), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
 
 
+def test_vpc_many_modules_large_histogram(mpc, oracle, configs, traces):
+    """16 modules at 128-byte lines: 17 clusters x 1030 bins = 70 KB of LDS histogram, more than a
+    kernel's default 64 KiB (fast kernel with the run-time module loop, and the generic kernel)."""
+    L = 128
+    lines = np.concatenate([traces.structured(2500, L, seed=3), traces.mixed(600, L), traces.random_u32(300, L),
+                            traces.zeros(10, L)])
+    mods = [{"name": "AllZero"}, {"name": "AllWordSame"}]
+    for i in range(14):
+        mods.append(configs.one_base(L, 0, bool(i & 1)) if i % 3 == 0 else
+                    configs.consecutive_base(L, 0, bool(i & 1)) if i % 3 == 1 else
+                    configs.diff_base(L, [max(j - 1 - (i % 4), 0) if j % 4 > i % 4 else max(4 * (j // 4) - 1, 0) for j in range(L)],
+                                      [i] * L, 0, bool(i & 1)))
+    cfg = configs.make_config(L, mods)
+    _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+    mods[2] = configs.one_base(L, 5, True)            # a non-zero root sends the configuration to the generic kernel
+    _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:1500], expect_path=mpc.MPC_PATH_VPC_GENERIC)
+
+
 def _random_windowed_config(configs, rng, L):
     """Random fast-path configuration: 1..6 prediction modules of random kinds; windowed base
     tables (base byte in the own or the previous 32-bit word, never ahead of the byte), random
