@@ -23,53 +23,27 @@
 namespace comp
 {
 
+// Totals every evaluator keeps (reference CompResult.h:24-86).  The text output lives in
+// CompResult.cpp.
 struct CompResult {
-  CompResult(unsigned lineSize) : LineSize(lineSize), OriginalSize(0), CompressedSize(0), CompRatio(0) {}
+  explicit CompResult(unsigned lineSize) : LineSize(lineSize) {}
   virtual ~CompResult() {}
 
-  virtual void Update(unsigned uncompSize, unsigned compSize, int selected = 0)
-  {
-    (void)selected;
-    OriginalSize += uncompSize;
-    CompressedSize += compSize;
-    CompRatio = (double)OriginalSize / (double)CompressedSize;
-  }
+  // one evaluated line (or word): running totals and ratio
+  virtual void Update(unsigned uncompSize, unsigned compSize, int selected = 0);
+
+  // "workload,original_size,compressed_size,compression_ratio," row, to stdout or appended to filePath
+  virtual void Print(std::string workloadName = "", std::string filePath = "");
+  virtual void PrintDetail(std::string workloadName = "", std::string filePath = "");
 
   // opens filePath for appending, writing `header` first if the file is new
-  static void openForAppend(std::ofstream &file, const std::string &filePath, const std::string &header)
-  {
-    if (!isFileExists(filePath)) {
-      file.open(filePath);
-      if (!file.is_open()) {
-        std::cout << "File is not open: \"" << filePath << "\"" << std::endl;
-        exit(1);
-      }
-      file << header;
-      file.close();
-    }
-    file.open(filePath, std::ios_base::app);
-  }
-
-  virtual void Print(std::string workloadName = "", std::string filePath = "")
-  {
-    std::ofstream file;
-    if (filePath != "") openForAppend(file, filePath, "workload,original_size,compressed_size,compression_ratio,\n");
-    std::ostream &stream = (filePath == "") ? std::cout : file;
-    stream << workloadName << "," << OriginalSize << "," << CompressedSize << "," << mpctext::num(CompRatio) << ","
-           << std::endl;
-  }
-
-  virtual void PrintDetail(std::string workloadName = "", std::string filePath = "")
-  {
-    (void)workloadName;
-    (void)filePath;
-  }
+  static void openForAppend(std::ofstream &file, const std::string &filePath, const std::string &header);
 
   std::string CompressorName;
   const unsigned LineSize;
-  uint64_t OriginalSize;
-  uint64_t CompressedSize;
-  double CompRatio;
+  uint64_t OriginalSize = 0;
+  uint64_t CompressedSize = 0;
+  double CompRatio = 0;
 };
 
 }  // namespace comp

@@ -19,53 +19,56 @@ typedef uint64_t addr_t;
 namespace trace
 {
 
+// request direction (reference Loader.h:17-22)
 enum rw_t { READ, WRITE, NA };
 
+// One memory request / cache line as the loaders hand it out (reference Loader.h:24-60).  The
+// driver allocates one object and passes it to every GetCacheline() call; the loader refills it.
 struct MemReq_t {
-  addr_t addr;
-  rw_t rw;
-  uint32_t reqSize;
-  std::vector<WORD_SIZE> data;
-  bool isEnd;
+  addr_t addr = 0;
+  rw_t rw = NA;
+  uint32_t reqSize = 0;            // payload bytes
+  std::vector<WORD_SIZE> data;     // the line
+  bool isEnd = false;              // raised by the read that runs off the trace
 
   virtual ~MemReq_t() {}
+
+  // back to the empty request
   virtual void Reset()
   {
-    addr = 0;
-    rw = NA;
-    reqSize = 0;
     data.clear();
+    addr = 0, reqSize = 0;
+    rw = NA;
     isEnd = false;
   }
-  void Set(MemReq_t &memReq) { *this = memReq; }
-  MemReq_t &operator=(MemReq_t &rhs)
+
+  // the reference copies through a non-const reference; both spellings are kept
+  MemReq_t &operator=(MemReq_t &other)
   {
-    addr = rhs.addr;
-    rw = rhs.rw;
-    reqSize = rhs.reqSize;
-    data = rhs.data;
-    isEnd = rhs.isEnd;
+    if (this != &other) {
+      data = other.data;
+      addr = other.addr, reqSize = other.reqSize;
+      rw = other.rw;
+      isEnd = other.isEnd;
+    }
     return *this;
   }
+  void Set(MemReq_t &other) { operator=(other); }
 };
 
+// Base class of the trace readers (reference Loader.h:62-88): opens the file in binary mode,
+// serves lines one at a time.
 class Loader
 {
 public:
-  Loader(const char *filePath) : m_FilePath(filePath)
-  {
-    m_FileStream.open(m_FilePath, std::ios_base::in | std::ios_base::binary);
-  }
-  Loader(const std::string filePath) : m_FilePath(filePath)
-  {
-    m_FileStream.open(filePath.c_str(), std::ios_base::in | std::ios_base::binary);
-  }
+  explicit Loader(const char *filePath) : m_FilePath(filePath ? filePath : "") { openStream(); }
+  explicit Loader(const std::string filePath) : m_FilePath(filePath) { openStream(); }
   virtual ~Loader() {}
 
-  virtual MemReq_t *GetCacheline(MemReq_t *) = 0;
-  virtual unsigned GetCachelineSize() = 0;
+  virtual MemReq_t *GetCacheline(MemReq_t *) = 0;      // fills and returns its argument
+  virtual unsigned GetCachelineSize() = 0;             // bytes per line
   virtual unsigned long long GetNumLines() = 0;
-  virtual void Reset() = 0;
+  virtual void Reset() = 0;                            // rewind
 
   // ADDITIVE.  Copies up to maxLines of the lines the per-line interface would
   // still deliver (i.e. honouring the loader's isEnd convention) into dst and
@@ -86,6 +89,9 @@ public:
 protected:
   const std::string m_FilePath;
   std::ifstream m_FileStream;
+
+private:
+  void openStream() { m_FileStream.open(m_FilePath.c_str(), std::ios_base::in | std::ios_base::binary); }
 };
 
 }  // namespace trace
