@@ -33,6 +33,7 @@ hipError_t mpc_launch_synth(void *, u64, unsigned, int, u64, u64, const uint32_t
 hipError_t mpc_launch_read_probe(const void *, u64, uint32_t *, int, hipStream_t);
 hipError_t mpc_launch_vpc_lane(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
 size_t mpc_vpc_lane_smem(const MpcVpcParams *);
+int mpc_vpc_lane_unrolled(const MpcVpcParams *);
 size_t mpc_vpc_generic_smem(const MpcVpcParams *);
 }
 
@@ -884,7 +885,9 @@ int mpc_config_describe(const char *json_text, char *out, size_t cap)
     s = "{\"L\": " + std::to_string(cfg.L) + ", \"M\": " + std::to_string(cfg.M) + ", \"n_pred\": " + std::to_string(cfg.n_pred) +
         ", \"has_aws\": " + (cfg.has_aws ? "true" : "false") + ", \"hist_bins\": " + std::to_string(cfg.hist_bins) + ", \"enc_bits\": [";
     for (size_t i = 0; i < cfg.enc_bits.size(); i++) s += (i ? ", " : "") + std::to_string(cfg.enc_bits[i]);
-    s += "], \"path\": \"" + std::string(plan.fast ? "fast" : "generic") + "\", \"why_generic\": \"" + plan.why_generic + "\", \"modules\": [";
+    s += "], \"path\": \"" + std::string(plan.fast ? "fast" : "generic") + "\", \"why_generic\": \"" + plan.why_generic +
+         "\", \"sequence\": \"" + std::string(!plan.fast ? "" : (mpc_vpc_lane_unrolled(&plan.params) ? "unrolled" : "run-time loop")) +
+         "\", \"modules\": [";
     for (int i = 0; i < cfg.M; i++) {
       const mpc::Module &m = cfg.modules[(size_t)i];
       s += (i ? ", " : "");

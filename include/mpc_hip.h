@@ -140,7 +140,8 @@ int mpc_stats_reset(mpc_handle *h);
 /* ---- configuration check without a device --------------------------------
  * Parses and validates a VPC configuration exactly as mpc_create_vpc does and
  * writes a JSON description (line size, modules, id bits, which kernel path the
- * configuration maps to and why) into out[cap].  Touches no HIP API.  Returns
+ * configuration maps to and why, whether the module sequence has an unrolled
+ * instantiation or runs in the fast kernel's run-time module loop) into out[cap].  Touches no HIP API.  Returns
  * 0, or the negative code mpc_create_vpc would return ({"error": ...}).     */
 int mpc_config_describe(const char *config_json_text, char *out, size_t cap);
 

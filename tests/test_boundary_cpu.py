@@ -35,7 +35,7 @@ def test_config_describe_matches_oracle_parse(mpc, configs, oracle):
     for L in (32, 64, 128):
         cfg = configs.probe_config(L)
         d = mpc.describe_config(cfg)
-        assert d["rc"] == 0 and d["path"] == "fast", d
+        assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "unrolled", d
         oc = oracle.config_from_json(cfg)
         assert d["L"] == oc.line_size and d["M"] == oc.num_modules
         assert d["enc_bits"] == [oc.enc_bits[k] for k in range(oc.num_modules + 1)]
