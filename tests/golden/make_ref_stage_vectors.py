@@ -47,6 +47,32 @@ def module_specs(L, rng):
     return specs
 
 
+# WeightBase tables whose weights are NOT powers of two, and extreme ones: the reference takes
+# (int)log2f(w), truncating toward zero (PredictorModule.cpp:30) -- 0.3 -> -1, 0.7 -> 0, 3.0 -> 1,
+# 5.5 -> 2, 300.0 -> 8 (the byte shifts out), 0.001 -> -9 (likewise)
+ODD_WEIGHTS = [0.3, 0.7, 3.0, 5.5, 300.0, 0.001, 1.0, 0.5, 1.5, 0.99, 1.99, 2.0, 4.01, 0.26, 0.24, 127.9,
+               128.0, 0.0079, 0.0078125, 255.0, 0.126]
+
+
+def weight_specs(L, rng):
+    """Appended after module_specs() with a generator of its own, so that the earlier vectors
+    stay byte-identical when this file is regenerated."""
+    ident_rows = [i // L for i in range(8 * L)]
+    ident_cols = [i % L for i in range(8 * L)]
+    base4 = [max(i - 4, 0) for i in range(L)]
+    specs = []
+    # windowed tables (previous word), two shift distances: the lane kernel's WeightBase forms
+    for pair in ((0.3, 0.7), (3.0, 1.0), (5.5, 0.7), (300.0, 1.99), (0.001, 0.99), (0.26, 0.24)):
+        specs.append(dict(kind=0, root=0, base=base4, weight=[pair[i % 2] for i in range(L)], cx=1,
+                          rows=ident_rows, cols=ident_cols))
+    # every listed weight somewhere in one table, arbitrary base bytes, both XOR flavours, roots 0 and 7
+    for root, cx in ((0, 0), (7, 1)):
+        rb = [int(x) for x in rng.integers(0, L, L)]
+        rw = [float(ODD_WEIGHTS[int(x)]) for x in rng.integers(0, len(ODD_WEIGHTS), L)]
+        specs.append(dict(kind=0, root=root, base=rb, weight=rw, cx=cx, rows=ident_rows, cols=ident_cols))
+    return specs
+
+
 def lines_for(L, rng):
     out = []
     out.append(rng.integers(0, 256, L, dtype=np.uint8))
@@ -71,10 +97,16 @@ def main():
     if R is None:
         raise SystemExit("oracle/_ref is not built (make -C oracle _ref)")
     rng = np.random.default_rng(20221)
+    rng_w = np.random.default_rng(20222)
     vectors = []
+    jobs = []
     for L in (32, 64, 128):
         specs = module_specs(L, rng)
         lines = lines_for(L, rng)
+        jobs.append((L, specs, lines))
+    for L, _, lines in list(jobs):
+        jobs.append((L, weight_specs(L, rng_w), lines))
+    for L, specs, lines in jobs:
         for s in specs:
             base = np.array(s.get("base", [0] * L), dtype=np.int32)
             weight = np.array(s.get("weight", [1.0] * L), dtype=np.float32)

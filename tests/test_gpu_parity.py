@@ -100,6 +100,29 @@ def test_vpc_lane_kernel_sequences(mpc, oracle, configs, traces, L):
     _check_vpc(mpc, oracle, odd, lines64[:3000], expect_path=mpc.MPC_PATH_VPC_GENERIC)
 
 
+def test_vpc_matches_reference_line_vectors(mpc, oracle):
+    """Whole lines of the BASELINE workloads against numbers the REFERENCE's compiled stage classes
+    produced (tests/golden/ref_line_vectors.json): the HIP path's selected module is the arg-max of the
+    reference's leading-zero-row counts with ties to the later module, and its size is that module's
+    reference encoder size + id bits, or 8 L + id bits when that is not smaller (VPC.cpp:366-415)."""
+    import ref_lines
+    cases = ref_lines.load_cases()
+    assert len(cases) >= 10
+    for name, cfg, lines, c in cases:
+        size, sel = ref_lines.expected_sizes(oracle, cfg, lines, c)
+        ev = mpc.VPC(cfg)
+        assert ev.kernel_path == mpc.MPC_PATH_VPC_FAST, name
+        s, k = ev.compress_lines(lines)
+        bad = np.nonzero((s != size) | (k != sel))[0]
+        assert bad.size == 0, (name, bad[:5], s[bad[:5]], size[bad[:5]], k[bad[:5]], sel[bad[:5]])
+        # and in shuffled order / a different position in the wave
+        perm = np.random.default_rng(3).permutation(len(lines))
+        ev.reset()
+        s, k = ev.compress_lines(lines[perm])
+        assert (s == size[perm]).all() and (k == sel[perm]).all(), name
+        ev.close()
+
+
 def test_vpc_known_answers_on_gpu(mpc, configs, traces):
     # SURVEY.md 8c known answers, straight from the HIP path
     ev = mpc.VPC(configs.probe_config(64))

@@ -170,6 +170,82 @@ def test_oracle_matches_live_reference_stages(oracle, configs):
                     lib.mpc_o_fpc_size(my_sc.ctypes.data, len(my_sc))
 
 
+def test_oracle_matches_live_reference_odd_weights(oracle):
+    """WeightBase tables with weights that are not powers of two and with extreme weights:
+    (int)log2f(w) truncates toward zero (PredictorModule.cpp:30).  Live against the reference's
+    compiled classes; the same kind of tables are also in the committed golden vectors."""
+    R = oracle.ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference tree not mounted)")
+    lib = oracle.lib()
+    rng = np.random.default_rng(4321)
+    weights = [0.3, 0.7, 3.0, 5.5, 300.0, 0.001, 1.0, 0.5, 1.5, 0.99, 1.99, 2.0, 4.01, 0.26, 0.24, 127.9,
+               128.0, 0.0079, 0.0078125, 255.0, 0.126, 1e-6, 1e6]
+    for L in (32, 64, 128):
+        for trial in range(40):
+            m = oracle.OModule()
+            m.kind, m.pred_kind = oracle.KIND_PREDCOMP, 0
+            m.root = int(rng.integers(0, L)) if trial % 2 else 0
+            m.consecutive_xor = trial % 3 != 0
+            for j in range(L):
+                m.base[j] = int(rng.integers(0, L)) if trial % 4 else max(j - 4, 0)
+                m.weight[j] = weights[int(rng.integers(0, len(weights)))]
+            m.table_size = 8 * L
+            for j in range(8 * L):
+                m.rows[j], m.cols[j] = j // L, j % L
+            base = np.array(list(m.base)[:L], dtype=np.int32)
+            weight = np.array(list(m.weight)[:L], dtype=np.float32)
+            diff = np.zeros(L, dtype=np.int32)
+            rows = np.array(list(m.rows)[: 8 * L], dtype=np.int32)
+            cols = np.array(list(m.cols)[: 8 * L], dtype=np.int32)
+            for k in range(25):
+                line = rng.integers(0, 256, L, dtype=np.uint8) if k % 2 else \
+                    (rng.integers(0, 256) + np.arange(L) * rng.integers(0, 3)).astype(np.uint8)
+                ref_p, my_p = np.zeros(L, np.uint8), np.zeros(L, np.uint8)
+                R.ref_predict(0, m.root, L, base.ctypes.data, weight.ctypes.data, diff.ctypes.data,
+                              line.ctypes.data, ref_p.ctypes.data)
+                lib.mpc_o_predict(C.byref(m), L, line.ctypes.data, my_p.ctypes.data)
+                assert (ref_p == my_p).all()
+                ref_sc, my_sc = np.zeros(8 * L // 16, np.uint16), np.zeros(8 * L // 16, np.uint16)
+                R.ref_scanned(0, m.root, L, base.ctypes.data, weight.ctypes.data, diff.ctypes.data,
+                              m.consecutive_xor, 8 * L, rows.ctypes.data, cols.ctypes.data, line.ctypes.data,
+                              ref_sc.ctypes.data)
+                lib.mpc_o_scanned(C.byref(m), L, line.ctypes.data, my_sc.ctypes.data)
+                assert (ref_sc == my_sc).all()
+
+
+# ------------------------------------------------- reference-derived whole-line vectors
+def test_oracle_matches_reference_line_vectors(oracle):
+    """Whole lines of the BASELINE workloads: per prediction module the oracle's scanned array has the
+    leading-zero-row count and the common-encoder size the reference's compiled classes produced
+    (tests/golden/ref_line_vectors.json), and the oracle's per-line (size, selected) is what the
+    selector / decision rule of VPC.cpp:366-415 gives on those reference numbers."""
+    import ref_lines
+    lib = oracle.lib()
+    cases = ref_lines.load_cases()
+    assert len(cases) >= 10
+    for name, cfg, lines, c in cases:
+        oc = oracle.config_from_json(cfg)
+        L = oc.line_size
+        rows = 8 * L // 16
+        z, enc = np.array(c["z"]), np.array(c["enc"])
+        sc = np.zeros(rows, np.uint16)
+        step = 1 if len(lines) <= 600 else 3          # the stage check on every third line of the long traces
+        for n in range(0, len(lines), step):
+            for q, mi in enumerate(c["module_index"]):
+                lib.mpc_o_scanned(C.byref(oc.modules[mi]), L, lines[n].ctypes.data, sc.ctypes.data)
+                nz = np.flatnonzero(sc)
+                assert (int(nz[0]) if len(nz) else rows) == z[n, q], (name, n, q)
+                assert lib.mpc_o_fpc_size(sc.ctypes.data, rows) == enc[n, q], (name, n, q)
+        size, sel = ref_lines.expected_sizes(oracle, cfg, lines, c)
+        s, k = oracle.VpcOracle(cfg).compress(lines)
+        assert (s == size).all() and (k == sel).all(), name
+        # the traces must keep exercising the selector: several modules win, and ties occur
+        if name.startswith("structured/64"):
+            assert len(set(sel.tolist())) >= 4
+            assert (np.sort(z, axis=1)[:, -1] == np.sort(z, axis=1)[:, -2]).any()
+
+
 # ------------------------------------------------------------ statistics plumbing
 def test_stats_consistency(oracle, configs, traces):
     v = oracle.VpcOracle(configs.probe_config(64))
