@@ -29,6 +29,19 @@ __device__ __forceinline__ u32 fold8(u32 x)          // OR of the 4 bytes
   x |= x >> 8;
   return x & 0xffu;
 }
+// v_bitop3_b32: any boolean function of three words in ONE instruction that issues at the fast VALU
+// rate on gfx950 (like v_xor / v_add; v_or3, v_and_or, v_bfi, v_xnor, v_cndmask issue 1.6x slower:
+// profiles/r01_valu_issue_rates_gfx950.txt).  TT = truth table with a = 0xF0, b = 0xCC, c = 0xAA.
+#define BO_A 0xF0u
+#define BO_B 0xCCu
+#define BO_C 0xAAu
+template <unsigned TT>
+__device__ __forceinline__ u32 bitop3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
+__device__ __forceinline__ u32 or3(u32 a, u32 b, u32 c) { return bitop3<(BO_A | BO_B | BO_C)>(a, b, c); }
+__device__ __forceinline__ u32 and_or(u32 a, u32 b, u32 c) { return bitop3<((BO_A & BO_B) | BO_C)>(a, b, c); }          // (a & b) | c
+__device__ __forceinline__ u32 mask_sel(u32 m, u32 a, u32 b) { return bitop3<0xCAu>(m, a, b); }   // m ? a : b, bitwise
+__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { return bitop3<(BO_A ^ BO_B ^ BO_C)>(a, b, c); }
+__device__ __forceinline__ u32 maj3(u32 a, u32 b, u32 c) { return bitop3<((BO_A & BO_B) | (BO_A & BO_C) | (BO_B & BO_C))>(a, b, c); }
 __device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ u32 alignbyte(u32 hi, u32 lo, u32 n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
 __device__ __forceinline__ u32 sum_bytes(u32 x, u32 acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }

@@ -237,13 +237,14 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
     u32 r[W], root_r;
     lane_residue<W, KIND>(c, P.fm[Q], P.tab, r, root_r);
     const u32 z = lane_leading_zero_rows<W>(r);
-    const bool take = !any_full || best.z <= z;     // ties go to the later module (VPC.cpp:389)
-    best.z = take ? z : best.z;
-    best.q = take ? Q : best.q;
-    best.root_r = take ? root_r : best.root_r;
-    best.cx = take ? (u32)P.fm[Q].cx : best.cx;
+    // ties go to the later module (VPC.cpp:389); the winner is kept with bit masks (v_bitop3_b32)
+    const u32 m = (!any_full || best.z <= z) ? ~0u : 0u;
+    best.z = mask_sel(m, z, best.z);
+    best.q = (int)mask_sel(m, (u32)Q, (u32)best.q);
+    best.root_r = mask_sel(m, root_r, best.root_r);
+    best.cx = mask_sel(m, (u32)P.fm[Q].cx, best.cx);
 #pragma unroll
-    for (int e = 0; e < W; e++) best.r[e] = take ? r[e] : best.r[e];
+    for (int e = 0; e < W; e++) best.r[e] = mask_sel(m, r[e], best.r[e]);
     any_full = true;
   }
   if constexpr (!last) lane_seq<W, NPT, Q + 1, REST...>(c, P, keep_bits, best, any_full);
@@ -376,45 +377,43 @@ __device__ __forceinline__ u32 encode_rows_x4(const u32 *t, u32 &Z)
     P[4 * e + 2] = perm(hi23, hi01, 0x05040100u);
     P[4 * e + 3] = perm(hi23, hi01, 0x07060302u);
   }
-  // per plane: S = bit set in >= 1 column, T = in >= 2, U = in >= 3 (carry-save tree over the columns)
-  u32 s1[8], t1[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    s1[i] = P[2 * i] | P[2 * i + 1];
-    t1[i] = P[2 * i] & P[2 * i + 1];
-  }
-  // two ones in adjacent columns c, c+1 (c = 0..14)
-  u32 A = t1[0] | t1[1] | t1[2] | t1[3] | t1[4] | t1[5] | t1[6] | t1[7];
-#pragma unroll
-  for (int i = 0; i < 7; i++) A |= P[2 * i + 1] & P[2 * i + 2];
-  const u32 Sf = s1[0] | s1[1] | s1[2] | s1[3];   // columns 0..7
-  const u32 Sb = s1[4] | s1[5] | s1[6] | s1[7];   // columns 8..15
-  const u32 S = Sf | Sb;
-  u32 s2[4], t2[4], u2[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const u32 sa = s1[2 * i], sb = s1[2 * i + 1], ta = t1[2 * i], tb = t1[2 * i + 1];
-    s2[i] = sa | sb;
-    t2[i] = ta | tb | (sa & sb);
-    u2[i] = (ta & sb) | (sa & tb);
-  }
-  u32 s3[2], t3[2], u3[2];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const u32 sa = s2[2 * i], sb = s2[2 * i + 1], ta = t2[2 * i], tb = t2[2 * i + 1];
-    s3[i] = sa | sb;
-    t3[i] = ta | tb | (sa & sb);
-    u3[i] = u2[2 * i] | u2[2 * i + 1] | (ta & sb) | (sa & tb);
-  }
-  const u32 T = t3[0] | t3[1] | (s3[0] & s3[1]);
-  const u32 U = u3[0] | u3[1] | (t3[0] & s3[1]) | (s3[0] & t3[1]);
-  const u32 single = S & ~T;             // exactly one 1: 7 bits
-  const u32 two = T & ~U & A;            // exactly two, adjacent: 8 bits
-  const u32 rest = S & ~single & ~two;
-  const u32 both = Sf & Sb;
-  const u32 half = rest & ~both;         // one 8-column half empty: 12 bits
-  const u32 full = rest & both;          // 17 bits
-  Z = ~S;
+  // Row classes from the number of ones per row (= per bit position, over the 16 packed columns).
+  // Carry-save adders (sum = a ^ b ^ c, carry = majority: one v_bitop3_b32 each): b0 = bit 0 of the
+  // count, b1 = bit 1, hi = the count is 4 or more.
+  u32 c2[8];                      // carries of weight 2
+  u32 s0, s1, s2, s3, s4;
+#define MPC_FA(S, C, a, b, c) { S = xor3(a, b, c); C = maj3(a, b, c); }
+  MPC_FA(s0, c2[0], P[0], P[1], P[2])
+  MPC_FA(s1, c2[1], P[3], P[4], P[5])
+  MPC_FA(s2, c2[2], P[6], P[7], P[8])
+  MPC_FA(s3, c2[3], P[9], P[10], P[11])
+  MPC_FA(s4, c2[4], P[12], P[13], P[14])
+  u32 s5, s6;
+  MPC_FA(s5, c2[5], s0, s1, s2)
+  MPC_FA(s6, c2[6], s3, s4, P[15])
+  const u32 b0 = s5 ^ s6;
+  c2[7] = s5 & s6;
+  u32 d0, d1, d2, c4a, c4b, c4c;
+  MPC_FA(d0, c4a, c2[0], c2[1], c2[2])
+  MPC_FA(d1, c4b, c2[3], c2[4], c2[5])
+  MPC_FA(d2, c4c, d0, d1, c2[6])
+#undef MPC_FA
+  const u32 b1 = d2 ^ c2[7];
+  const u32 hi = or3(c4a, c4b, c4c) | (d2 & c2[7]);
+  // two ones in adjacent columns c, c+1 (c = 0..14): (P[c] & P[c+1]) | (P[c+1] & P[c+2]) is one bitop3
+  constexpr unsigned ADJ = (BO_A & BO_B) | (BO_B & BO_C);
+  const u32 A = or3(or3(bitop3<ADJ>(P[0], P[1], P[2]), bitop3<ADJ>(P[2], P[3], P[4]), bitop3<ADJ>(P[4], P[5], P[6])),
+                    or3(bitop3<ADJ>(P[6], P[7], P[8]), bitop3<ADJ>(P[8], P[9], P[10]), bitop3<ADJ>(P[10], P[11], P[12])),
+                    and_or(P[14], P[15], bitop3<ADJ>(P[12], P[13], P[14])));
+  const u32 Sf = or3(or3(P[0], P[1], P[2]), or3(P[3], P[4], P[5]), P[6] | P[7]);        // columns 0..7
+  const u32 Sb = or3(or3(P[8], P[9], P[10]), or3(P[11], P[12], P[13]), P[14] | P[15]);  // columns 8..15
+  const u32 single = bitop3<(BO_A & ~BO_B & ~BO_C) & 0xFFu>(b0, b1, hi);    // exactly one 1: 7 bits
+  const u32 cnt2 = bitop3<(~BO_A & BO_B & ~BO_C) & 0xFFu>(b0, b1, hi);     // exactly two
+  const u32 two = cnt2 & A;                                                // ... adjacent: 8 bits
+  const u32 rest = bitop3<(BO_A | (BO_B & ~BO_C)) & 0xFFu>(and_or(b0, b1, hi), cnt2, A);   // three or more, or two apart
+  const u32 half = bitop3<(BO_A & ~(BO_B & BO_C)) & 0xFFu>(rest, Sf, Sb);  // one 8-column half empty: 12 bits
+  const u32 full = bitop3<(BO_A & BO_B & BO_C)>(rest, Sf, Sb);             // 17 bits
+  Z = ~(Sf | Sb);
   return 7u * __popc(single) + 8u * __popc(two) + 12u * __popc(half) + 17u * __popc(full);
 }
 
@@ -455,6 +454,7 @@ struct LaneRun {
   u32 key;     // (cluster + 1) << 16 | size
   u32 cnt;
   u32 acc_r, acc_r2;
+  bool enc_hot;   // wave-uniform: the previous group of this wave had lines the common encoder compressed
 };
 
 __device__ __forceinline__ void lane_run_flush(const LaneRun &rs, const WgStats &st, int K, int bins)
@@ -578,13 +578,16 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
         t[e] = best.r[e] ^ (e == 0 ? (f & 0xffffff00u) : f);
       }
     }
+    // The certificate pays where it closes every line of the group (incompressible data); where the
+    // previous group of this wave still had compressible lines it is skipped and the encoder runs
+    // straight away (rs.enc_hot, wave-uniform).
     bool open = need;
-    if constexpr (!(MPC_ABLATE & 2)) open = need && !lane_certified<W>(t);
-    else open = need && (t[0] == 12345u);
+    if (!rs.enc_hot) open = need && !lane_certified<W>(t);
     u32 enc = uncomp;
     if (__ballot(open)) enc = lane_encode<W>(t);
     const bool keep = open && enc < uncomp && !no_pred;             // VPC.cpp:397-407
     const u64 keep_mask = __ballot(keep);
+    rs.enc_hot = keep_mask != 0;
 
     // residue statistics over all positions: the winner's residues (the root position
     // holds best.root_r, not the raw root), or the raw bytes when the line stays
@@ -605,9 +608,10 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
       return;
     }
     u32 w[W];
+    const u32 km = keep ? ~0u : 0u;
 #pragma unroll
-    for (int e = 0; e < W; e++) w[e] = keep ? best.r[e] : c.x[e];
-    w[0] = keep ? ((w[0] & 0xffffff00u) | best.root_r) : w[0];
+    for (int e = 0; e < W; e++) w[e] = mask_sel(km, best.r[e], c.x[e]);
+    w[0] = mask_sel(km & 0xffu, best.root_r, w[0]);
     byte_sums<W>(w, sum_r, sum_r2);
     sum_r = need ? sum_r : 0u;
     sum_r2 = need ? sum_r2 : 0u;
@@ -640,8 +644,12 @@ __device__ __forceinline__ void lane_fetch(uint4 (&v)[NQ], const uint4 *__restri
 }
 
 // n_lines < 2^31 per launch (the host splits larger batches)
+// 64-byte lines and shorter: 4 workgroups (16 waves) per CU, i.e. at most 128 VGPRs
+#ifndef MPC_LB_WAVES
+#define MPC_LB_WAVES 4
+#endif
 template <int W, bool OUT, int... KINDS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (W <= 16 ? MPC_LB_WAVES : 1))
 vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
                 uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats)
 {
@@ -662,7 +670,7 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
   E.sizes_out = sizes_out;
   E.sel_out = sel_out;
 
-  LaneRun rs = {0xffffffffu, 0, 0, 0};
+  LaneRun rs = {0xffffffffu, 0, 0, 0, false};
   u32 iter = 0;
 
   // wave-uniform first line of the wave's group of 64: the address math stays on the scalar unit
@@ -736,9 +744,11 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
                        first_line, *P, d_sizes, d_sel, d_stats);                                                   \
   }
   switch (P->L) {
+#ifndef MPC_DEV_ONLY64     // development builds (tools/ablate.sh): 64-byte lines only, seconds to compile
   case 32: MPC_LAUNCH(8); break;
-  case 64: MPC_LAUNCH(16); break;
   case 128: MPC_LAUNCH(32); break;
+#endif
+  case 64: MPC_LAUNCH(16); break;
   default: return hipErrorInvalidValue;
   }
 #undef MPC_LAUNCH
@@ -750,8 +760,12 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
 #define WTP (MPC_FK_WEIGHT | LK_PW)
 #define DFQ (MPC_FK_DIFF | LK_PW2)
 #define WTQ (MPC_FK_WEIGHT | LK_PW2)
+#ifdef MPC_DEV_ONLY64
+#define MPC_LANE_SEQUENCES(X) X(OB, CS, DFP, WTP)
+#else
 #define MPC_LANE_SEQUENCES(X) \
   X(OB, CS, DFP, WTP) X(OB, CS, DFQ, WTQ) X(OB, CS, DF, WT) X(OB, CS) X(OB) X(CS) X(DF) X(WT) X(DFP) X(WTP)
+#endif
 
 }  // namespace
 
