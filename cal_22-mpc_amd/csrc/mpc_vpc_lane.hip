@@ -196,16 +196,39 @@ struct LaneBest {
   int q;
   u32 root_r;
   u32 cx;
+  u32 encb;    // id bits of the winner's cluster (wave-uniform scalar loads, selected per lane: an
+               // indexed read of the kernel arguments per lane would be a vector load + full wait)
 };
 
 // ---- module sequence -------------------------------------------------------------
 // Pass 1: row-0 prefilters of all modules but the last -> wave-uniform bit mask of the
-// modules that have to be evaluated (bit Q: some needed line has a clear row 0).
+// modules that have to be evaluated (bit Q: enough needed lines have a clear row 0).
+//
+// Deferral.  A module that only a few lines of the group can win with would still be evaluated
+// for all 64 lanes.  When at most MPC_DEFER_MAX lines pass a module's prefilter (and the wave's
+// queue has room), those LINES are set aside instead -- their index goes to the wave's queue in
+// LDS and they take no further part in this group -- and the module is skipped for the group.
+// Queued lines are evaluated later, 64 at a time, with every module they need (drain groups:
+// no deferral there).  The result of a line does not depend on which way it went: the prefilter
+// only ever skips modules that cannot win.
+#ifndef MPC_DEFER_MAX
+#define MPC_DEFER_MAX 8
+#endif
+constexpr u32 kDeferCap = 512;      // queue entries per wave (2 KiB of LDS)
+constexpr u32 kDeferHigh = 384;     // the streaming loop hands over to a drain above this many entries
+
+// LDS bytes of the statistics: as vpc_stats_smem plus the spare histogram slot deferred lines are parked in
+__host__ __device__ static inline size_t lane_stats_smem(int K, int bins)
+{
+  return 16 * (size_t)((2 * K * 8 + 15) / 16) + 16 * (size_t)(((K * bins + 1) * 4 + 15) / 16);
+}
+
 template <int W, int NPT, int Q>
-__device__ __forceinline__ u32 lane_prefilters(const Lane<W> &, const MpcVpcParams &, u64) { return 0; }
+__device__ __forceinline__ u32 lane_prefilters(const Lane<W> &, const MpcVpcParams &, u64 &, u64 &, bool) { return 0; }
 
 template <int W, int NPT, int Q, int KIND, int... REST>
-__device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcParams &P, u64 need_mask)
+__device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcParams &P, u64 &need_mask, u64 &defer_mask,
+                                               bool allow_defer)
 {
   if constexpr (Q + 1 == NPT) {
     return 0;
@@ -216,15 +239,23 @@ __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcPar
       u32 msb = lane_row0<W, KIND, 0, 3>(c, P.fm[Q], P.tab);
       if ((__ballot(msb != 0) & need_mask) != need_mask) {
         msb |= lane_row0<W, KIND, 3, 4>(c, P.fm[Q], P.tab);
-        bit = ((__ballot(msb != 0) & need_mask) != need_mask) ? (1u << Q) : 0u;
+        const u64 pass = ~__ballot(msb != 0) & need_mask;
+        if (pass) {
+          if (MPC_DEFER_MAX > 0 && allow_defer && __popcll(pass) <= MPC_DEFER_MAX) {
+            defer_mask |= pass;
+            need_mask &= ~pass;
+          } else {
+            bit = 1u << Q;
+          }
+        }
       }
     }
-    return bit | lane_prefilters<W, NPT, Q + 1, REST...>(c, P, need_mask);
+    return bit | lane_prefilters<W, NPT, Q + 1, REST...>(c, P, need_mask, defer_mask, allow_defer);
   }
 }
 
 // Pass 2 (only when pass 1 kept a module): the kept modules and the last one in order,
-// winner updated with selects.
+// winner updated with bit masks (v_bitop3_b32).
 template <int W, int NPT, int Q>
 __device__ __forceinline__ void lane_seq(const Lane<W> &, const MpcVpcParams &, u32, LaneBest<W> &, bool) {}
 
@@ -237,12 +268,13 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
     u32 r[W], root_r;
     lane_residue<W, KIND>(c, P.fm[Q], P.tab, r, root_r);
     const u32 z = lane_leading_zero_rows<W>(r);
-    // ties go to the later module (VPC.cpp:389); the winner is kept with bit masks (v_bitop3_b32)
+    // ties go to the later module (VPC.cpp:389)
     const u32 m = (!any_full || best.z <= z) ? ~0u : 0u;
     best.z = mask_sel(m, z, best.z);
     best.q = (int)mask_sel(m, (u32)Q, (u32)best.q);
     best.root_r = mask_sel(m, root_r, best.root_r);
     best.cx = mask_sel(m, (u32)P.fm[Q].cx, best.cx);
+    best.encb = mask_sel(m, (u32)P.enc_bits[P.start + Q + 1], best.encb);
 #pragma unroll
     for (int e = 0; e < W; e++) best.r[e] = mask_sel(m, r[e], best.r[e]);
     any_full = true;
@@ -261,6 +293,7 @@ __device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &
     lane_residue<W, KIND>(c, P.fm[Q], P.tab, best.r, best.root_r);
     best.q = Q;
     best.cx = (u32)P.fm[Q].cx;
+    best.encb = (u32)P.enc_bits[P.start + Q + 1];
   } else {
     lane_last<W, NPT, Q + 1, REST...>(c, P, best);
   }
@@ -275,6 +308,7 @@ __device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcP
   best.q = -1;
   best.root_r = 0;
   best.cx = 0;
+  best.encb = 0;
 #pragma unroll
   for (int e = 0; e < W; e++) best.r[e] = 0;
   for (int q = 0; q < P.n_pred; q++) {
@@ -302,6 +336,7 @@ __device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcP
     best.q = take ? q : best.q;
     best.root_r = take ? root_r : best.root_r;
     best.cx = take ? (u32)fm.cx : best.cx;
+    best.encb = take ? (u32)P.enc_bits[P.start + q + 1] : best.encb;
 #pragma unroll
     for (int e = 0; e < W; e++) best.r[e] = take ? r[e] : best.r[e];
   }
@@ -478,6 +513,7 @@ struct LaneEnv {
   u64 first_line;
   uint16_t *sizes_out;
   int8_t *sel_out;
+  u32 *defer_q;      // this wave's queue of deferred lines (LDS, kDeferCap entries)
 };
 
 // sum and sum of squares of the bytes of W words (two chains each: the reductions are
@@ -511,18 +547,23 @@ __device__ __forceinline__ void lane_run_add(LaneRun &rs, u32 key, u32 sum_r, u3
   rs.acc_r2 += sum_r2;
 }
 
-// one group of 64 lines: lane i evaluates line line0 + i, held in v[].  FULL: all 64 lines
-// exist (every group but the last one of a launch), which keeps EXEC untouched on the way.
-template <int W, bool OUT, bool FULL, int... KINDS>
-__device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, const MpcVpcParams &P, const LaneEnv &E,
-                                          LaneRun &rs)
+// one group of 64 lines, held in v[].  Streaming groups (DRAIN = false): lane i evaluates line
+// line0 + i; FULL: all 64 lines exist (every group but the last one of a launch), which keeps EXEC
+// untouched on the way; lines that only a rarely useful module could win with may be set aside into
+// the wave's queue (qn = entries waiting, wave-uniform).  Drain groups (DRAIN = true): this lane
+// evaluates queued line `dline` if `dvalid`, with every module it needs.
+template <int W, bool OUT, bool FULL, bool DRAIN, int... KINDS>
+__device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u32 dline, bool dvalid, const MpcVpcParams &P,
+                                          const LaneEnv &E, LaneRun &rs, u32 &qn)
 {
   constexpr int L = 4 * W;
   constexpr int NQ = W / 4;
   constexpr int NPT = sizeof...(KINDS);
   constexpr u32 uncomp = 8u * L;
-  const bool valid = FULL ? true : (line0 + E.lane < E.n_lines);
-  const u64 valid_mask = FULL ? ~0ull : __ballot(valid);
+  const bool valid = DRAIN ? dvalid : (FULL ? true : (line0 + E.lane < E.n_lines));
+  const u64 valid_mask = (FULL && !DRAIN) ? ~0ull : __ballot(valid);
+  const u32 line = DRAIN ? dline : line0 + E.lane;
+  bool deferred = false;
   Lane<W> c;
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
@@ -538,8 +579,8 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
     is_rep = diff == 0;                       // every word equals word 0
     is_zero = (diff | c.x[0]) == 0;
   }
-  const bool need = valid && !(is_zero || (P.has_aws && is_rep));
-  const u64 need_mask = __ballot(need);
+  bool need = valid && !(is_zero || (P.has_aws && is_rep));
+  u64 need_mask = __ballot(need);
 
   int chosen = is_zero ? 0 : 1;
   u32 size = is_zero ? E.enc_zero : E.enc_same;
@@ -550,7 +591,16 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
     c.rootb = perm(c.x[0], c.x[0], 0u);
     LaneBest<W> best;
     if constexpr (NPT > 0) {
-      const u32 keep_bits = lane_prefilters<W, NPT, 0, KINDS...>(c, P, need_mask);
+      u64 defer_mask = 0;
+      const bool allow_defer = !DRAIN && qn + (u32)((NPT - 1) * MPC_DEFER_MAX) <= kDeferCap;
+      const u32 keep_bits = lane_prefilters<W, NPT, 0, KINDS...>(c, P, need_mask, defer_mask, allow_defer);
+      if (!DRAIN && defer_mask) {          // wave-uniform and rare: some lines leave for the queue
+        deferred = (defer_mask >> E.lane) & 1ull;
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(defer_mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)defer_mask, 0u));
+        if (deferred) E.defer_q[qn + rank] = line;
+        qn += (u32)__popcll(defer_mask);
+        need = need && !deferred;
+      }
       if (keep_bits == 0) lane_last<W, NPT, 0, KINDS...>(c, P, best);
       else lane_seq<W, NPT, 0, KINDS...>(c, P, keep_bits, best, false);
     } else {
@@ -600,9 +650,9 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
       if (valid) lane_run_add(rs, unc_size, sum_r, sum_r2, E);       // cluster -1: key = size
       if constexpr (OUT) {
         if (valid) {
-          const u64 line = E.first_line + line0 + E.lane;
-          if (E.sizes_out) E.sizes_out[line] = (uint16_t)unc_size;
-          if (E.sel_out) E.sel_out[line] = (int8_t)-1;
+          const u64 at = E.first_line + line;
+          if (E.sizes_out) E.sizes_out[at] = (uint16_t)unc_size;
+          if (E.sel_out) E.sel_out[at] = (int8_t)-1;
         }
       }
       return;
@@ -617,19 +667,23 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, co
     sum_r2 = need ? sum_r2 : 0u;
     if (need) {
       chosen = keep ? P.start + best.q : -1;
-      size = keep ? enc + (u32)P.enc_bits[chosen + 1] : unc_size;
+      size = keep ? enc + best.encb : unc_size;
     }
   }
 
   // ---- statistics: run-length per lane ----
-  if (valid) lane_run_add(rs, ((u32)(chosen + 1) << 16) | size, sum_r, sum_r2, E);
+  // a deferred line is counted when it is drained; here it goes to a spare histogram slot behind
+  // the last cluster (index K * bins, never flushed), which keeps EXEC whole
+  u32 key = ((u32)(chosen + 1) << 16) | size;
+  if (!DRAIN) key = deferred ? ((u32)E.K << 16) : key;
+  if (valid) lane_run_add(rs, key, sum_r, sum_r2, E);
 
   // ---- per-line outputs (parity mode) ----
   if constexpr (OUT) {
-    if (valid) {
-      const u64 line = E.first_line + line0 + E.lane;
-      if (E.sizes_out) E.sizes_out[line] = (uint16_t)size;
-      if (E.sel_out) E.sel_out[line] = (int8_t)chosen;
+    if (valid && !deferred) {
+      const u64 at = E.first_line + line;
+      if (E.sizes_out) E.sizes_out[at] = (uint16_t)size;
+      if (E.sel_out) E.sel_out[at] = (int8_t)chosen;
     }
   }
 }
@@ -661,6 +715,7 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
   E.st.sums = reinterpret_cast<u64 *>(smem);
   E.st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * E.K * 8 + 15) / 16));
   stats_init(E.st, E.K, E.bins);   // ends with __syncthreads()
+  E.defer_q = reinterpret_cast<u32 *>(smem + lane_stats_smem(E.K, E.bins)) + (threadIdx.x >> 6) * kDeferCap;
   E.enc_zero = (u32)P.enc_bits[1];
   E.enc_same = 32u + (u32)P.enc_bits[2];
   E.enc_unc = (u32)P.enc_bits[0];
@@ -680,23 +735,37 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
 
   // two line buffers: the next group of 64 lines is in flight while this one is evaluated
   uint4 va[NQ], vb[NQ];
-  if (line0 < n_lines) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
-  while (line0 < n_lines) {
-    lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
-    if (line0 + 64u <= n_lines) lane_step<W, OUT, true, KINDS...>(va, line0, P, E, rs);
-    else lane_step<W, OUT, false, KINDS...>(va, line0, P, E, rs);
-    line0 += stride;
-    if (line0 >= n_lines) break;
-    lane_fetch<NQ>(va, lines, line0 + stride + E.lane, n_lines);
-    if (line0 + 64u <= n_lines) lane_step<W, OUT, true, KINDS...>(vb, line0, P, E, rs);
-    else lane_step<W, OUT, false, KINDS...>(vb, line0, P, E, rs);
-    line0 += stride;
-    if ((++iter & 127u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
-      lane_run_flush(rs, E.st, E.K, E.bins);
-      rs.cnt = 0;
-      rs.acc_r = 0;
-      rs.acc_r2 = 0;
+  u32 qn = 0;          // deferred lines waiting in the wave's queue (wave-uniform)
+  for (;;) {
+    // ---- streaming: until the trace ends or the queue is nearly full ----
+    if (line0 < n_lines && qn <= kDeferHigh) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
+    while (line0 < n_lines && qn <= kDeferHigh) {
+      lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
+      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(va, line0, 0u, true, P, E, rs, qn);
+      else lane_step<W, OUT, false, false, KINDS...>(va, line0, 0u, true, P, E, rs, qn);
+      line0 += stride;
+      if (line0 >= n_lines) break;
+      lane_fetch<NQ>(va, lines, line0 + stride + E.lane, n_lines);
+      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(vb, line0, 0u, true, P, E, rs, qn);
+      else lane_step<W, OUT, false, false, KINDS...>(vb, line0, 0u, true, P, E, rs, qn);
+      line0 += stride;
+      if ((++iter & 127u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
+        lane_run_flush(rs, E.st, E.K, E.bins);
+        rs.cnt = 0;
+        rs.acc_r = 0;
+        rs.acc_r2 = 0;
+      }
     }
+    // ---- drain: the queued lines, 64 at a time from the top of the queue ----
+    while (qn > 0u) {
+      const u32 take = qn < 64u ? qn : 64u;
+      qn -= take;
+      const bool dvalid = E.lane < take;
+      const u32 dline = dvalid ? E.defer_q[qn + E.lane] : 0u;
+      lane_fetch<NQ>(va, lines, dline, n_lines);
+      lane_step<W, OUT, false, true, KINDS...>(va, 0u, dline, dvalid, P, E, rs, qn);
+    }
+    if (line0 >= n_lines) break;
   }
   lane_run_flush(rs, E.st, E.K, E.bins);
   stats_flush(E.st, E.K, E.bins, gstats);
@@ -778,7 +847,8 @@ extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P)
   return 0;
 }
 
-extern "C" size_t mpc_vpc_lane_smem(const MpcVpcParams *P) { return vpc_stats_smem(P->M + 1, P->hist_bins); }
+// statistics + the four waves' queues of deferred lines
+extern "C" size_t mpc_vpc_lane_smem(const MpcVpcParams *P) { return lane_stats_smem(P->M + 1, P->hist_bins) + 4u * kDeferCap * sizeof(u32); }
 
 extern "C" hipError_t mpc_launch_vpc_lane(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
                                           int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
