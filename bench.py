@@ -13,7 +13,12 @@ by the one real exchange of the path: a sum all-reduce (RCCL) of the integer
 statistics vector.  Lines shard contiguously over ranks (weak scaling: the
 per-GPU shard is fixed, config.workload names it); there is no other collective.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Beside the headline fields (BASELINE configs[1]:
+random-uint32 64 B blocks) the line carries, outside the timed region,
+  "workloads": N = 1 -- the other BASELINE workloads (fp32 sine, mixed int/fp, zeros,
+               128 B pointer qwords) through VPC and BDI: kernel, kernel_ms_avg, roofline, ratio;
+  "config4":   N > 1 -- BASELINE configs[3] (mixed int/fp, 512 Mi blocks per GPU, sharded
+               contiguously, one all-reduce per pass): rccl_ranks, pass time, all-reduce share.
 """
 import argparse
 import ctypes
@@ -48,7 +53,8 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0, 
     kind = WORKLOADS[workload][0]
     gen = {"random_u32": traces.random_u32, "sine_f32": traces.sine_f32, "mixed": traces.mixed,
            "zeros": traces.zeros, "pointers_u64": traces.pointers_u64}[kind]
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    host_cores = len(os.sched_getaffinity(0))      # cores this process may run on
+    cores = max(1, min(host_cores, 16))            # threads actually started (capped at 16)
     cfg = configs.probe_config(L)
     make = {"VPC": lambda: O.VpcOracle(cfg), "BDI": lambda: O.BdiOracle(L), "FPC": lambda: O.FpcOracle(L), "BPC": lambda: O.BpcOracle(L)}[algo]
     # calibrate on a short run, then size the sample for ~`seconds` of wall time
@@ -68,10 +74,66 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0, 
     for t in ths:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": cores * per_thread / dt, "unit": "blocks/s", "cores": cores, "kind": "port",
+    return {"value": cores * per_thread / dt, "unit": "blocks/s", "cores": cores, "host_cores": host_cores,
+            "thread_cap": 16, "kind": "port",
             "sample": f"{per_thread} {workload} {L} B blocks per thread x {cores} threads "
                       f"(oracle/mpc_oracle.c, {'probe config' if algo == 'VPC' else algo}), {dt:.1f} s",
             "single_core_blocks_per_s": rate1}
+
+
+def kernel_label(mpc, ev, algo: str, L: int) -> str:
+    if algo == "BDI":
+        return f"bdi_kernel<{L // 4}>"
+    if algo == "FPC":
+        return f"fpc_kernel<{L // 4}>"
+    if algo == "BPC":
+        return f"bpc_kernel<{L // 4}>"
+    if ev.kernel_path == mpc.MPC_PATH_VPC_FAST:
+        return f"vpc_lane_kernel<{L // 4}>"        # one lane per line, W = L/4 words
+    return "vpc_generic_kernel"
+
+
+def make_evaluator(mpc, configs, algo: str, L: int, device: int):
+    if algo == "VPC":
+        return mpc.VPC(configs.probe_config(L), device=device)
+    return {"BDI": mpc.BDI, "FPC": mpc.FPC, "BPC": mpc.BPC}[algo](L, device=device)
+
+
+def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, bytes_total, first_line=0, steps=5):
+    """One sub-record: `workload` generated into (a prefix of) buf, `steps` launches timed with HIP events on
+    the launch stream, the evaluator's own statistics checked for the line count."""
+    kind, L = WORKLOADS[workload]
+    n = bytes_total // L
+    mpc.synth_fill(buf.data_ptr(), n, L, kind, first_line=first_line)
+    torch.cuda.synchronize()
+    ev = make_evaluator(mpc, configs, algo, L, device)
+    sp = stream.cuda_stream
+    ev.compress_device(buf.data_ptr(), n, stream=sp)       # warm-up
+    torch.cuda.synchronize()
+    ev.reset()
+    ms = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        ev.compress_device(buf.data_ptr(), n, stream=sp)
+        b.record(stream)
+        torch.cuda.synchronize()
+        ms.append(a.elapsed_time(b))
+    v = ev.stats_vector()
+    assert int(v[0]) == n * steps, (workload, algo, int(v[0]), n * steps)
+    avg = sum(ms) / len(ms)
+    achieved = n * L / (avg / 1e3) / 1e9
+    rec = {"workload": workload, "algorithm": algo, "line_size": L, "blocks": n, "kernel": kernel_label(mpc, ev, algo, L),
+           "kernel_ms_avg": avg, "kernel_ms_min": min(ms), "blocks_per_s": n / (avg / 1e3),
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": n * L},
+           "compression_ratio": float(v[1]) / float(v[2])}
+    ev.close()
+    return rec
+
+
+SUB_WORKLOADS = [("sine_f32", "VPC"), ("mixed", "VPC"), ("zeros", "VPC"), ("pointers_u64_128", "VPC"),
+                 ("random_u32", "BDI"), ("sine_f32", "BDI"), ("mixed", "BDI"), ("pointers_u64_128", "BDI")]
 
 
 def main():
@@ -83,6 +145,10 @@ def main():
     ap.add_argument("--lines", type=int, default=256 << 20, help="blocks per GPU (default 256 Mi = 16 GiB at 64 B)")
     ap.add_argument("--algo", default="VPC", choices=["VPC", "BDI", "FPC", "BPC"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="skip the sub-records of the other BASELINE workloads (sine, mixed, zeros, 128 B pointers; VPC and BDI)")
+    ap.add_argument("--config4-lines", type=int, default=512 << 20,
+                    help="N > 1: blocks per GPU of the BASELINE config 4 sub-record (mixed int/fp, 4 Gi blocks over 8 GPUs)")
     ap.add_argument("--rehearse-single-gpu", action="store_true",
                     help="development: run the N>1 code path with every rank on cuda:0 and the gloo backend "
                          "(a 1-GPU box cannot host an RCCL group); never used for reported numbers")
@@ -122,14 +188,7 @@ def main():
     buf = torch.empty(n * L, dtype=torch.uint8, device=dev)
     mpc.synth_fill(buf.data_ptr(), n, L, kind, first_line=rank * n)
     torch.cuda.synchronize()
-    if args.algo == "VPC":
-        ev = mpc.VPC(configs.probe_config(L), device=local_rank)
-    elif args.algo == "BDI":
-        ev = mpc.BDI(L, device=local_rank)
-    elif args.algo == "FPC":
-        ev = mpc.FPC(L, device=local_rank)
-    else:
-        ev = mpc.BPC(L, device=local_rank)
+    ev = make_evaluator(mpc, configs, args.algo, L, local_rank)
     # a real (non-default) stream: the kernel is launched on it through the C ABI and
     # the HIP events that time it are recorded on the same stream
     stream = torch.cuda.Stream(device=dev)
@@ -191,16 +250,59 @@ def main():
         probe_ms.append(a.elapsed_time(b))
     probe_gbps = n * L / (min(probe_ms[1:]) / 1e3) / 1e9
 
-    if args.algo == "BDI":
-        kernel_name = f"bdi_kernel<{L // 4}>"
-    elif args.algo == "FPC":
-        kernel_name = f"fpc_kernel<{L // 4}>"
-    elif args.algo == "BPC":
-        kernel_name = f"bpc_kernel<{L // 4}>"
-    elif ev.kernel_path == mpc.MPC_PATH_VPC_FAST:
-        kernel_name = f"vpc_lane_kernel<{L // 4}>"        # one lane per line, W = L/4 words
-    else:
-        kernel_name = "vpc_generic_kernel"
+    kernel_name = kernel_label(mpc, ev, args.algo, L)
+
+    # ---- sub-records (not part of the timed region above) ----
+    # N = 1: every other BASELINE workload through the same entry point, VPC and BDI, 16 GiB each.
+    workloads = None
+    if world == 1 and not args.no_workloads:
+        workloads = []
+        for wl, algo in SUB_WORKLOADS:
+            if (wl, algo) == (args.workload, args.algo):
+                continue
+            workloads.append(time_workload(torch, mpc, configs, buf, stream, local_rank, wl, algo, n * L))
+    # N > 1: BASELINE config 4 -- mixed int/fp blocks sharded contiguously over the ranks, one RCCL
+    # all-reduce of the statistics per pass -- as its own sub-record next to the primary value (which
+    # stays on the N = 1 workload so that the scaling curve is comparable).
+    config4 = None
+    if world > 1:
+        n4 = min(args.config4_lines, args.lines) if args.rehearse_single_gpu else args.config4_lines
+        del buf
+        torch.cuda.empty_cache()
+        buf4 = torch.empty(n4 * 64, dtype=torch.uint8, device=dev)
+        mpc.synth_fill(buf4.data_ptr(), n4, 64, "mixed", first_line=rank * n4)
+        torch.cuda.synchronize()
+        ev4 = make_evaluator(mpc, configs, "VPC", 64, local_rank)
+        scratch4 = torch.zeros(ev4.stats_raw_len(), dtype=torch.int64, device=dev)
+        ks, ke, se = [], [], []
+        for i in range(1 + 5):
+            a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            a.record(stream)
+            ev4.compress_device(buf4.data_ptr(), n4, stream=sp)
+            b.record(stream)
+            sharded.all_reduce_raw_on_device(ev4, scratch4, sp)
+            c.record(stream)
+            torch.cuda.synchronize()
+            if i:
+                ks.append(a.elapsed_time(b))
+                se.append(a.elapsed_time(c))
+        last4 = ev4.stats_from_raw(scratch4.cpu().numpy().view(np.uint64))
+        assert int(last4[0]) == world * n4 * 6, (int(last4[0]), world * n4 * 6)
+        t4 = torch.tensor([sum(se) / len(se), sum(ks) / len(ks)], dtype=torch.float64,
+                          device="cpu" if args.rehearse_single_gpu else dev)
+        dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+        step_ms, kern_ms4 = float(t4[0]), float(t4[1])
+        config4 = {"workload": f"{world * n4} mixed int/fp 64 B blocks, {n4} per GPU, VPC probe config",
+                   "sharding": f"contiguous x{world}", "rccl_ranks": dist.get_world_size(),
+                   "collective": "one SUM all-reduce of the uint64 statistics accumulators per pass"
+                                 + (" (gloo rehearsal)" if args.rehearse_single_gpu else " (RCCL)"),
+                   "ms_per_pass": step_ms, "kernel_ms_avg": kern_ms4,
+                   "all_reduce_share_of_pass": max(0.0, 1.0 - kern_ms4 / step_ms),
+                   "blocks_per_s": world * n4 / (step_ms / 1e3),
+                   "roofline_frac_per_gpu": n4 * 64 / (kern_ms4 / 1e3) / 1e9 / HBM_PEAK_GBPS,
+                   "compression_ratio": float(last4[1]) / float(last4[2])}
+        ev4.close()
+
     if rank == 0:
         traffic = args.traffic_bytes
         if traffic is None:
@@ -239,6 +341,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(configs, traces, args.workload, L, algo=args.algo)
         else:
             out["cpu_baseline"] = None
+        if workloads is not None:
+            # HBM bytes per launch from the separate rocprofv3 --pmc passes recorded in profiles/traffic.json
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    tj = json.load(f)
+            except OSError:
+                tj = {}
+            for w in workloads:
+                w["roofline"]["traffic"] = tj.get(f"{w['algorithm']}/{w['workload']}/{w['line_size']}/{w['blocks']}", {}).get("bytes")
+            out["workloads"] = workloads
+        if config4 is not None:
+            out["config4"] = config4
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -612,3 +612,39 @@ def test_two_rank_sharded_npy(mpc, oracle, configs, traces, tmp_path):
     o.compress(lines[:-1])
     for r in range(2):
         assert (np.load(tmp_path / f"tot_{r}.npy") == o.stats_vector()).all()
+
+
+def test_bench_two_rank_rehearsal_child_process():
+    """bench.py's N > 1 path (contiguous shards, the all-reduce of the device accumulators, the
+    max-over-ranks timing, the config 4 sub-record) run as a FRESH child process under
+    torch.distributed.run -- two ranks on the one GPU of this box with the gloo backend (an RCCL group
+    needs one GPU per rank).  The line-count assertions inside bench.py must hold and the JSON line
+    must carry the N > 1 fields."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--rehearse-single-gpu", "--lines", "1048576", "--steps", "2", "--warmup", "1"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.split("\n") if l.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["blocks_per_gpu"] == 1048576 and d["config"]["sharding"] == "contiguous x2"
+    assert d["value"] > 0 and d["roofline"]["kernel"] == "vpc_lane_kernel<16>"
+    c4 = d["config4"]
+    assert c4["rccl_ranks"] == 2 and c4["sharding"] == "contiguous x2"
+    assert 0.0 <= c4["all_reduce_share_of_pass"] < 1.0 and c4["blocks_per_s"] > 0
+    # random u32 blocks stay uncompressed at 515 bits, mixed blocks compress
+    assert abs(d["config"]["compression_ratio"] - 512.0 / 515.0) < 1e-6
+    assert c4["compression_ratio"] > 1.0
