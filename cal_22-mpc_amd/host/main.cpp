@@ -21,7 +21,7 @@
 #include "VPC.h"
 #include "utils.h"
 
-static comp::CompResult *compressLines(comp::Compressor *compressor, trace::Loader *loader);
+static comp::CompResult *compressLines(comp::Compressor *compressor, trace::Loader *loader, bool perLine);
 
 static const char *kHelp =
     "Usage:\n"
@@ -38,6 +38,7 @@ static const char *kHelp =
 struct Args {
   std::string algorithm, input, config, output;
   bool has_algorithm = false, has_input = false, has_config = false, has_output = false, help = false;
+  bool per_line = false;   // ADDITIVE --per-line: the reference's loop (GetCacheline -> CompressLine per line) instead of batches
 };
 
 static bool take_value(int argc, char **argv, int &i, const std::string &arg, const char *shortf, const char *longf,
@@ -72,6 +73,7 @@ int main(int argc, char **argv)
   for (int i = 1; i < argc; i++) {
     const std::string arg = argv[i];
     if (arg == "-h" || arg == "--help") { a.help = true; continue; }
+    if (arg == "--per-line") { a.per_line = true; continue; }
     if (take_value(argc, argv, i, arg, "-a", "algorithm", a.algorithm, a.has_algorithm)) continue;
     if (take_value(argc, argv, i, arg, "-i", "input", a.input, a.has_input)) continue;
     if (take_value(argc, argv, i, arg, "-c", "config", a.config, a.has_config)) continue;
@@ -128,7 +130,7 @@ int main(int argc, char **argv)
   const std::string compOutputSavePath = outputDirPath + "/" + saveFileName + "_results.csv";
   const std::string compDetailedOutputSavePath = outputDirPath + "/" + saveFileName + "_results_detail.csv";
 
-  comp::CompResult *compStat = compressLines(compressor, loader);
+  comp::CompResult *compStat = compressLines(compressor, loader, a.per_line);
 
   // workload name = <parent directory>_<file stem> (reference main.cpp:141-157)
   std::string workloadName;
@@ -157,14 +159,14 @@ int main(int argc, char **argv)
 
 // The reference's per-line loop (main.cpp:208-248) as a batch loop: stream the file
 // through the evaluator when the loader allows it, else pull batches, else lines.
-static comp::CompResult *compressLines(comp::Compressor *compressor, trace::Loader *loader)
+static comp::CompResult *compressLines(comp::Compressor *compressor, trace::Loader *loader, bool perLine)
 {
   if (compressor->GetLineSize() != loader->GetCachelineSize()) {
     printf("The trace has %u-byte lines but the evaluator is configured for %u-byte lines.\n",
            loader->GetCachelineSize(), compressor->GetLineSize());
     exit(1);
   }
-  const std::string path = loader->GetStreamablePath();
+  const std::string path = perLine ? std::string() : loader->GetStreamablePath();
   if (!path.empty()) {
     compressor->CompressFile(path);
     return compressor->GetResult();
@@ -172,18 +174,25 @@ static comp::CompResult *compressLines(comp::Compressor *compressor, trace::Load
   const unsigned L = loader->GetCachelineSize();
   const unsigned long long cap = (64ull << 20) / L;
   std::vector<uint8_t> buf((size_t)(cap * L));
-  if (loader->SupportsBatch()) {
+  if (!perLine && loader->SupportsBatch()) {
     for (;;) {
       unsigned long long n = loader->GetBatch(buf.data(), cap);
       if (n == 0) break;
       compressor->CompressBatch(buf.data(), n);
     }
   } else {
-    trace::MemReq_t *memReq = new trace::MemReq_t;
+    // the reference's loop (main.cpp:208-248): one request object handed back and forth, a .log
+    // trace's requests filtered to GLOBAL_ACC_R / GLOBAL_ACC_W (main.cpp:222-224)
+    trace::gpgpusim::LoaderGPGPU *gpgpu = dynamic_cast<trace::gpgpusim::LoaderGPGPU *>(loader);
+    trace::MemReq_t *memReq = gpgpu ? new trace::gpgpusim::MemReqGPU_t : new trace::MemReq_t;
     memReq->Reset();
     while (1) {
       memReq = loader->GetCacheline(memReq);
       if (memReq->isEnd) break;
+      if (gpgpu) {
+        const trace::gpgpusim::reqTypeGPU t = static_cast<trace::gpgpusim::MemReqGPU_t *>(memReq)->reqType;
+        if (!(t == trace::gpgpusim::GLOBAL_ACC_R || t == trace::gpgpusim::GLOBAL_ACC_W)) continue;
+      }
       compressor->CompressLine(memReq->data);
     }
   }

@@ -1,6 +1,7 @@
 // utils.h -- small helpers of the CLI (reference src/utils.{h,cpp}) plus the text
 // formatting the reference gets from {fmt}: "{}" of a double is the shortest
-// round-trip representation, which std::to_chars produces as well.
+// round-trip representation in fixed notation for decimal exponents -4 .. 15,
+// exponent notation otherwise (mpctext::num).
 #ifndef MPC_HOST_UTILS_H
 #define MPC_HOST_UTILS_H
 

@@ -140,3 +140,23 @@ def test_element_configs_are_fast_path(mpc, configs, oracle):
         assert configs.element_config(L, 4) == configs.probe_config(L)
         assert configs.element_config(L, 8) == configs.probe_config_u64(L)
 
+
+
+def test_npy_header_malformed_is_an_error_code(mpc, tmp_path):
+    """Hand-made .npy headers that end inside a key's value must come back as an error code from the C ABI,
+    never as a C++ exception escaping an extern "C" function (std::terminate would take the host down)."""
+    import struct
+
+    def write(name, header: bytes):
+        p = tmp_path / name
+        p.write_bytes(b"\x93NUMPY\x01\x00" + struct.pack("<H", len(header)) + header)
+        return str(p)
+    rows, cols = C.c_uint64(), C.c_uint64()
+    bad = [b"{'descr': '|u1', 'fortran_order':", b"{'descr': '|u1', 'fortran_order':     ", b"{'descr': '|u1",
+           b"{'descr': '|u1', 'fortran_order': False, 'shape': (3, 64", b"{}", b"",
+           b"{'descr': '|u1', 'fortran_order': True, 'shape': (3, 64), }"]
+    for i, h in enumerate(bad):
+        rc = mpc.lib().mpc_npy_shape(write(f"bad{i}.npy", h).encode(), C.byref(rows), C.byref(cols))
+        assert rc < 0, (i, h, rc)
+    ok = write("ok.npy", b"{'descr': '|u1', 'fortran_order': False, 'shape': (3, 64), }" + b" " * 10 + b"\n")
+    assert mpc.lib().mpc_npy_shape(ok.encode(), C.byref(rows), C.byref(cols)) == 0 and (rows.value, cols.value) == (3, 64)

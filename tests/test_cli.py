@@ -268,3 +268,64 @@ def test_cli_line_size_mismatch_is_an_error(cli, configs, traces, tmp_path):
     cfg_path = configs.write_config(configs.probe_config(64), str(tmp_path / "c.json"))
     r = run([cli, "-a", "VPC", "-i", p, "-c", cfg_path, "-o", str(tmp_path)])
     assert r.returncode == 1 and "32-byte lines" in r.stdout
+
+
+@pytest.mark.gpu
+def test_per_line_drop_in_matches_batch(cli, oracle, configs, traces, tmp_path):
+    """The reference driver's own loop, unchanged (main.cpp:208-248): GetCacheline -> isEnd -> CompressLine per
+    line -> GetResult -> Print / PrintDetail, driven (a) by tests/native/perline_probe.cpp through comp::VPC /
+    comp::BDI and (b) by `compressor --per-line`.  Every returned size equals the oracle's and the CSV text
+    equals what the batch path writes for the same trace (.npy and GPGPU-Sim .log)."""
+    host = os.path.join(ROOT, "cal_22-mpc_amd", "host")
+    probe = str(tmp_path / "perline_probe")
+    srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp") and f != "main.cpp"]
+    b = subprocess.run(["hipcc", "-O2", "-std=c++17", "-I", host, "-I", os.path.join(ROOT, "include"), "-o", probe,
+                        os.path.join(ROOT, "tests", "native", "perline_probe.cpp"), *srcs,
+                        "-L", os.path.join(ROOT, "cal_22-mpc_amd"), "-lmpc_hip",
+                        "-Wl,-rpath," + os.path.join(ROOT, "cal_22-mpc_amd")], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-3000:]
+    ds = tmp_path / "probe"
+    ds.mkdir()
+    lines = np.concatenate([traces.structured(1500, 64, seed=31), traces.mixed(600, 64), traces.random_u32(200, 64),
+                            traces.zeros(20, 64), traces.word_same(20, 64), traces.bdi_stress(280, 64)])
+    lines = lines[np.random.default_rng(12).permutation(len(lines))]
+    p = traces.save_npy(str(ds / "trace.npy"), lines)
+    cfg = configs.probe_config(64)
+    cfg_path = configs.write_config(cfg, str(tmp_path / "probe64.json"))
+    for algo, make in (("VPC", lambda: oracle.VpcOracle(cfg)), ("BDI", lambda: oracle.BdiOracle(64))):
+        # (a) the C++ classes through the reference-shaped loop
+        out = tmp_path / f"pl_{algo}"
+        out.mkdir()
+        r = run([probe, algo, cfg_path if algo == "VPC" else "-", p, str(out / "r.csv"), str(out / "d.csv"), str(out / "s.bin")])
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "lines/s" in r.stdout
+        o = make()
+        s_ref = o.compress(lines[:-1])[0]                      # LoaderNPY flags the last row as the end
+        got = np.fromfile(out / "s.bin", dtype=np.uint16)
+        assert len(got) == len(lines) - 1 and (got == s_ref).all()
+        # (b) the CLI with the per-line loop against the CLI's batch path: identical files
+        ob, op = tmp_path / f"batch_{algo}", tmp_path / f"perline_{algo}"
+        ob.mkdir()
+        op.mkdir()
+        extra = ["-c", cfg_path] if algo == "VPC" else []
+        rb = run([cli, "-a", algo, "-i", p, "-o", str(ob)] + extra)
+        rp = run([cli, "-a", algo, "-i", p, "-o", str(op), "--per-line"] + extra)
+        assert rb.returncode == 0 and rp.returncode == 0, rb.stdout + rp.stdout + rp.stderr
+        assert rb.stdout == rp.stdout
+        stem = "probe64" if algo == "VPC" else "BDI"
+        assert (ob / f"{stem}_results.csv").read_text() == (op / f"{stem}_results.csv").read_text()
+        if algo == "VPC":
+            assert (ob / f"{stem}_results_detail.csv").read_text() == (op / f"{stem}_results_detail.csv").read_text()
+            # the probe's own rows (workload name "probe_trace") carry the same numbers
+            assert (out / "r.csv").read_text().split("\n")[2] == (ob / f"{stem}_results.csv").read_text().split("\n")[2]
+            assert (out / "d.csv").read_text().split("\n")[2] == (ob / f"{stem}_results_detail.csv").read_text().split("\n")[2]
+    # GPGPU-Sim .log through the per-line loop: the driver-side request filter (main.cpp:222-224)
+    types = np.random.default_rng(3).integers(0, 9, 1200)
+    plog = traces.write_gpgpusim_log(str(ds / "k.log"), lines[:1200], types)
+    ob, op = tmp_path / "batch_log", tmp_path / "perline_log"
+    ob.mkdir()
+    op.mkdir()
+    rb = run([cli, "-a", "VPC", "-i", plog, "-c", cfg_path, "-o", str(ob)])
+    rp = run([cli, "-a", "VPC", "-i", plog, "-c", cfg_path, "-o", str(op), "--per-line"])
+    assert rb.returncode == 0 and rp.returncode == 0 and rb.stdout == rp.stdout
+    assert (ob / "probe64_results_detail.csv").read_text() == (op / "probe64_results_detail.csv").read_text()

@@ -148,3 +148,33 @@ def test_oracle_under_sanitizers(tmp_path):
                                                    os.path.join(ROOT, "oracle", "mpc_oracle.c"), "-lm"])
     r = subprocess.run([probe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr[-3000:]
+
+
+def test_double_text_matches_fmt_layout(tmp_path):
+    """mpctext::num lays doubles out like {fmt}'s "{}" (what the reference's CSV writers use): shortest
+    round-trip digits, fixed notation for decimal exponents -4 .. 15, d.ddde[+-]XX otherwise.  The expected
+    strings are {fmt}'s documented behaviour; Python's repr follows the same rule apart from a trailing
+    ".0", which makes it a second witness on random values."""
+    probe = _build(str(tmp_path), "num_probe", ["g++", "-std=c++17", *SAN, "-I", HOST, os.path.join(NATIVE, "num_probe.cpp"),
+                                                os.path.join(HOST, "utils.cpp")])
+    known = {0.0001: "0.0001", 0.0005: "0.0005", 1e5: "100000", 3e5: "300000", 1e16: "1e+16", 1e-5: "1e-05",
+             1e15: "1000000000000000", 170.66666666666666: "170.66666666666666", 0.9941747572815534: "0.9941747572815534",
+             3.0: "3", 0.0: "0", 1.5e-7: "1.5e-07", 123456789012345680.0: "1.2345678901234568e+17", 0.00012345: "0.00012345",
+             64.0 / (64 * 2000): "0.0005", 2.5: "2.5", 1e100: "1e+100", 1234.5e-9: "1.2345e-06", -0.25: "-0.25"}
+    rng = np.random.default_rng(11)
+    rand = [float(x) for x in np.concatenate([rng.random(300) * 10.0 ** rng.integers(-9, 18, 300),
+                                              rng.integers(1, 1 << 40, 200) / rng.integers(1, 1 << 20, 200)])]
+
+    def fmt_like(x):
+        r = repr(x)
+        if "e" in r:
+            m, e = r.split("e")
+            return (m[:-2] if m.endswith(".0") else m) + "e" + e
+        return r[:-2] if r.endswith(".0") else r
+    vals = list(known) + rand
+    r = subprocess.run([probe] + [float(v).hex() for v in vals], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout.strip().split("\n")
+    assert len(out) == len(vals)
+    for v, got in zip(vals, out):
+        assert got == known.get(v, fmt_like(v)), (v, got)
