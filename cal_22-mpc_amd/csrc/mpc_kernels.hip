@@ -503,28 +503,13 @@ fpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
 // plane 32 down: zero-DBX runs (3 bits for one plane, 7 for 2..33), zero DBP 5, all ones
 // (0x7fffffff, i.e. only with 31 deltas) 5, one 1 / two adjacent 1s 10, anything else 32
 // bits; the first word always costs 3 + 4 bits (BPC.cpp:96-108 assigns in its first test).
-// One lane per line: the R x 32 bit matrix of the delta words (R = 8, 16, 32 rows incl. one
-// zero row) is transposed with a butterfly network of masked swaps, then the planes are
-// walked in registers.
+//
+// One lane per line, and no bit transpose: the planes are classified where they lie.  Per delta r
+// the word X_r = d_r ^ (d_r >> 1) (33-bit shift) holds bit c of DBX[c] at bit c, so "how many ones
+// has DBX[c]" is a count per bit POSITION over the X_r -- carry-save adders on v_bitop3_b32, all 32
+// low planes at once -- "two adjacent ones" is the OR of X_r & X_(r+1), "DBP[c] == 0" the OR of the
+// d_r, "all ones" their AND.  Plane 32 (the borrows) is a single word and handled on its own.
 // ---------------------------------------------------------------------------
-template <int R>
-__device__ __forceinline__ void bit_transpose_blocks(u32 (&A)[R])     // R x R blocks side by side, LSB indexing
-{
-  constexpr int STAGES = R == 32 ? 5 : (R == 16 ? 4 : 3);
-#pragma unroll
-  for (int st = 0; st < STAGES; st++) {
-    const int j = (R / 2) >> st;
-    const u32 m = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u;
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-      if (k & j) continue;
-      const u32 t = ((A[k] >> j) ^ A[k + j]) & m;
-      A[k + j] ^= t;
-      A[k] ^= t << j;
-    }
-  }
-}
-
 template <int NW>   // words per line: 8, 16 or 32
 __global__ void __launch_bounds__(256)
 bpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ sizes_out,
@@ -533,7 +518,7 @@ bpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
   __shared__ u64 s_counts[MPC_BPC_RAW_LEN];
   if (threadIdx.x < MPC_BPC_RAW_LEN) s_counts[threadIdx.x] = 0;
   __syncthreads();
-  constexpr int ND = NW - 1;                           // deltas = rows of the bit matrix (row NW-1 is zero)
+  constexpr int ND = NW - 1;                           // deltas = bits of a plane
   u64 even = 0, odd = 0;                               // pattern counts 0,2,4,6 / 1,3,5 in 16-bit fields
   u64 words_acc = 0, bits_acc = 0;
   u32 since_flush = 0;
@@ -556,52 +541,79 @@ bpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
       const uint4 q = src[i];
       w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
     }
-    // deltas: low 32 bits in A[r], bit 32 (the borrow) collected into plane 32
-    u32 A[NW], top = 0;
+    // deltas (low words d_r, sign s_r = 0 / ~0 = bits 32.. of the 33-bit delta) and X_r
+    u32 X[ND];
+    u32 orD = 0, andX = ~0u, top = 0, adj = 0;
+    u32 b0 = 0, b1 = 0, hi = 0, pend = 0;       // ones per plane: bit 0, bit 1, "4 or more"; a waiting carry of weight 2
 #pragma unroll
     for (int r = 0; r < ND; r++) {
-      A[r] = w[r + 1] - w[r];
-      top |= (w[r + 1] < w[r] ? 1u : 0u) << r;
+      const u32 d = w[r + 1] - w[r];
+      const u32 sgn = w[r + 1] < w[r] ? ~0u : 0u;
+      X[r] = d ^ __builtin_amdgcn_alignbit(sgn, d, 1);          // d ^ ((sign : d) >> 1)
+      top = bitop3<((BO_A & BO_B) | BO_C)>(sgn, 1u << r, top);  // plane 32: bit r = the borrow of delta r
+      orD |= d;
+      if (ND == 31) andX &= X[r];
     }
-    A[ND] = 0;
-    bit_transpose_blocks<NW>(A);
-    // plane c: bits (c % NW) of block c / NW
-    u32 length = 3 + 4, run = 0, total_words = 0;
-    u64 pc = 0;                        // this line's pattern counts, 8-bit fields
-    u32 above = 0;                     // DBP of the plane above
 #pragma unroll
-    for (int c = 32; c >= 0; c--) {
-      u32 dbp;
-      if (c == 32) dbp = top;
-      else if constexpr (NW == 32) dbp = A[c];
-      else dbp = (A[c % NW] >> (NW * (c / NW))) & ((1u << NW) - 1u);
-      const u32 dbx = c == 32 ? dbp : (dbp ^ above);
-      above = dbp;
-      const bool nz = dbx != 0u;
-      // a non-zero plane closes the zero run before it
-      const u32 zrl = run == 0u ? 0u : (run == 1u ? 3u : 7u);
-      const u32 ones = (u32)__popc(dbx);
-      const bool allones = ND == 31 && dbx == 0x7fffffffu;
-      const bool two = ones == 2u && (dbx & (dbx >> 1)) != 0u;
-      const u32 pat = dbp == 0u ? 2u : allones ? 6u : ones == 1u ? 3u : two ? 4u : 0u;
-      const u32 cost = (dbp == 0u || allones) ? 5u : (ones == 1u || two) ? 10u : 32u;
-      if (nz) {
-        length += zrl + cost;
-        total_words += run + 1u;
-        pc += (1ull << (8u * pat)) + (run ? (1ull << 8) : 0ull);
-        run = 0;
+    for (int r = 0; r + 1 < ND; r += 2) {
+      // two more planes-words into the count: full adder at weight 1, its carry joins the weight-2 column
+      const u32 s = xor3(b0, X[r], X[r + 1]), c = maj3(b0, X[r], X[r + 1]);
+      b0 = s;
+      if ((r / 2) & 1) {
+        const u32 s2 = xor3(b1, pend, c), c4 = maj3(b1, pend, c);
+        b1 = s2;
+        hi |= c4;
       } else {
-        run++;
+        pend = c;
+      }
+      adj = bitop3<((BO_A & BO_B) | BO_C)>(X[r], X[r + 1], adj);
+      if (r + 2 < ND) adj = bitop3<((BO_A & BO_B) | BO_C)>(X[r + 1], X[r + 2], adj);
+    }
+    {
+      // ND is odd (7, 15, 31): one X left, and possibly a waiting carry
+      constexpr int last = ND - 1;
+      const u32 c = b0 & X[last];
+      b0 ^= X[last];
+      if ((((ND - 1) / 2) & 1) != 0) {          // a carry is waiting
+        const u32 s2 = xor3(b1, pend, c), c4 = maj3(b1, pend, c);
+        b1 = s2;
+        hi |= c4;
+      } else {
+        hi |= b1 & c;
+        b1 ^= c;
       }
     }
-    if (run) {
-      length += run == 1u ? 3u : 7u;
-      total_words += run;
-      pc += 1ull << 8;
-    }
-    even += pc & 0x00ff00ff00ff00ffull;
-    odd += (pc >> 8) & 0x00ff00ff00ff00ffull;
-    words_acc += total_words;
+    // classes of the 32 low planes, as bit masks (bit c = plane c)
+    const u32 nz = or3(b0, b1, hi);                                   // DBX[c] != 0
+    const u32 single = bitop3<(BO_A & ~BO_B & ~BO_C) & 0xFFu>(b0, b1, hi);
+    const u32 two = bitop3<(~BO_A & BO_B & ~BO_C) & 0xFFu>(b0, b1, hi) & adj;
+    const u32 zero_dbp = nz & ~orD;                                   // DBP[c] == 0 is tested first (BPC.cpp:127)
+    const u32 allones = ND == 31 ? (nz & orD & andX) : 0u;            // then DBX[c] == 0x7fffffff
+    const u32 rest = nz & ~zero_dbp & ~allones;
+    const u32 one_two = rest & (single | two);
+    const u32 unc = rest & ~(single | two);
+    // plane 32: DBX[32] = DBP[32] = the borrows
+    const u32 t_ones = (u32)__popc(top);
+    const bool t_nz = top != 0u;
+    const bool t_all = ND == 31 && top == 0x7fffffffu;
+    const bool t_one = !t_all && t_ones == 1u;
+    const bool t_two = !t_all && t_ones == 2u && (top & (top >> 1)) != 0u;
+    const bool t_unc = t_nz && !t_all && !t_one && !t_two;
+    // zero-DBX runs in coding order 32 .. 0: bit c of Z = DBX[c] == 0
+    const u64 Z = ((u64)(t_nz ? 0u : 1u) << 32) | (u64)(~nz);
+    const u64 starts = Z & ~(Z >> 1);                 // the plane above is not zero (or there is none)
+    const u64 longer = starts & (Z << 1);             // ... and the plane below is zero too: a run of 2 or more
+    const u32 n_runs = (u32)__popcll(starts);
+    const u32 n_zero = (u32)__popc(zero_dbp), n_all = (u32)__popc(allones) + (t_all ? 1u : 0u);
+    const u32 n_one = (u32)__popc(rest & single) + (t_one ? 1u : 0u);
+    const u32 n_two = (u32)__popc(rest & two & ~single) + (t_two ? 1u : 0u);
+    const u32 n_unc = (u32)__popc(unc) + (t_unc ? 1u : 0u);
+    (void)one_two;
+    const u32 length = 3u + 4u + 3u * n_runs + 4u * (u32)__popcll(longer) + 5u * (n_zero + n_all) + 10u * (n_one + n_two) + 32u * n_unc;
+    // BPCPattern order: Uncomp, ZRLE, Zero, SingleOne, ConsecTwoOnes, ZeroDBP (never), AllOnes
+    even += (u64)n_unc | ((u64)n_zero << 16) | ((u64)n_two << 32) | ((u64)n_all << 48);
+    odd += (u64)n_runs | ((u64)n_one << 16);
+    words_acc += 33u;                                  // every plane is counted once: as a pattern or inside a run
     bits_acc += length;
     if (sizes_out) sizes_out[line] = (uint16_t)length;
     if (sel_out) sel_out[line] = 0;
