@@ -508,8 +508,9 @@ int mpc_create_bdi(unsigned line_size, int device, mpc_handle **out)
 {
   if (!out) return MPC_E_INVAL;
   *out = nullptr;
-  if (!(line_size == 32 || line_size == 64 || line_size == 128)) {
-    g_create_error = "BDI line size must be 32, 64 or 128 bytes";
+  // BDI.cpp:8 takes any dataLine.size(); values are 8, 4 and 2 bytes wide, so a multiple of 8
+  if (line_size < 8 || line_size > MPC_MAX_LINE || (line_size % 8)) {
+    g_create_error = "BDI line size must be a multiple of 8 in 8.." + std::to_string(MPC_MAX_LINE) + " bytes";
     return MPC_E_INVAL;
   }
   mpc_handle *h = new (std::nothrow) mpc_handle();
@@ -532,8 +533,9 @@ int mpc_create_bpc(unsigned line_size, int device, mpc_handle **out)
 {
   if (!out) return MPC_E_INVAL;
   *out = nullptr;
-  if (!(line_size == 32 || line_size == 64 || line_size == 128)) {
-    g_create_error = "BPC line size must be 32, 64 or 128 bytes";
+  // 32-bit words; a plane has one bit per delta and is held in an int32_t (BPC.cpp:53-63): 2..32 words
+  if (line_size < 8 || line_size > 128 || (line_size % 4)) {
+    g_create_error = "BPC line size must be a multiple of 4 in 8..128 bytes";
     return MPC_E_INVAL;
   }
   mpc_handle *h = new (std::nothrow) mpc_handle();
@@ -556,8 +558,8 @@ int mpc_create_fpc(unsigned line_size, int device, mpc_handle **out)
 {
   if (!out) return MPC_E_INVAL;
   *out = nullptr;
-  if (!(line_size == 32 || line_size == 64 || line_size == 128)) {
-    g_create_error = "FPC line size must be 32, 64 or 128 bytes";
+  if (line_size < 4 || line_size > MPC_MAX_LINE || (line_size % 4)) {
+    g_create_error = "FPC line size must be a multiple of 4 in 4.." + std::to_string(MPC_MAX_LINE) + " bytes";
     return MPC_E_INVAL;
   }
   mpc_handle *h = new (std::nothrow) mpc_handle();

@@ -5,8 +5,8 @@
 
 #include <stdint.h>
 
-#define MPC_MAX_MODULES 16        /* M (AllZero + AllWordSame + prediction modules) */
-#define MPC_MAX_PRED    15        /* prediction (PredComp) modules */
+#define MPC_MAX_MODULES 32        /* M (AllZero + AllWordSame + prediction modules) */
+#define MPC_MAX_PRED    31        /* prediction (PredComp) modules */
 #define MPC_MAX_LINE    256       /* bytes per line, generic path */
 
 /* fast-path predictor forms (see DESIGN.md "Fast path") */

@@ -628,6 +628,126 @@ bpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// BDI / FPC / BPC at line sizes without an unrolled kernel (the reference takes any line a loader
+// hands it: BDI.cpp:8, FPC.cpp:10, BPC.cpp:35).  One lane per line, byte and word loops straight
+// from the definitions; exact, slow, and only ever used for line sizes other than 32 / 64 / 128.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool gen_bdi_fits(u64 x, int D)     // reduceSign(x) <= 2^(8D)-1, see bdi_fits64
+{
+  const u64 lim = D == 4 ? 0xffffffffull : ((1ull << (8 * D)) - 1ull);
+  const long long sx = (long long)x, h = 1ll << (8 * D - 1);
+  return x <= lim || (sx >= -h && sx <= -2);
+}
+
+__device__ u32 gen_bdi_check(const uint8_t *d, int L, int B, int D)   // BDI.cpp:108-201
+{
+  const u32 n = (u32)(L / B);
+  u32 imm = 0;
+  bool have_base = false, not_all = false;
+  u64 base = 0;
+  for (u32 i = 0; i < n; i++) {
+    u64 v = 0;
+    for (int j = B - 1; j >= 0; j--) v = (v << 8) | d[i * B + j];
+    const bool is_imm = gen_bdi_fits(v, D);
+    imm += is_imm ? 1u : 0u;
+    if (!is_imm) {
+      if (!have_base) { base = v; have_base = true; }
+      else if (!gen_bdi_fits(base - v, D)) not_all = true;
+    }
+  }
+  if (not_all) return n + 8u * ((imm * (u32)D) + ((n - imm) * (u32)B));
+  return n + 8u * ((imm * (u32)D) + ((u32)B + (n - imm - 1u) * (u32)D));     // 32-bit wrap when every value is an immediate
+}
+
+__global__ void __launch_bounds__(128)
+baseline_generic_kernel(int algo, const uint8_t *__restrict__ lines, u64 n_lines, int L, uint16_t *__restrict__ sizes_out,
+                        int8_t *__restrict__ sel_out, u64 *gstats)
+{
+  __shared__ u64 s_counts[16];
+  if (threadIdx.x < 16) s_counts[threadIdx.x] = 0;
+  __syncthreads();
+  for (u64 line = (u64)blockIdx.x * blockDim.x + threadIdx.x; line < n_lines; line += (u64)gridDim.x * blockDim.x) {
+    uint8_t d[MPC_MAX_LINE];
+    const uint8_t *src = lines + line * (u64)L;
+    for (int i = 0; i < L; i++) d[i] = src[i];
+    u32 size = 0;
+    int select = 0;
+    if (algo == 1) {                       // ---- BDI (BDI.cpp:6-74)
+      bool zeros = true, rep = true;
+      for (int i = 0; i < L; i++) zeros = zeros && d[i] == 0;
+      for (int i = 8; i < (L / 8) * 8; i++) rep = rep && d[i] == d[i % 8];
+      u32 best = 8u * (u32)L;
+      select = 8;
+      if (zeros) { best = 8; select = 0; }
+      else if (rep) { best = 64; select = 1; }
+      else {
+        const int combos[6][2] = {{8, 1}, {8, 2}, {8, 4}, {4, 1}, {4, 2}, {2, 1}};
+        for (int k = 0; k < 6; k++) {
+          const u32 c = gen_bdi_check(d, L, combos[k][0], combos[k][1]);
+          if (best > c) { best = c; select = 2 + k; }
+        }
+        if (best == 8u * (u32)L) select = 8;
+      }
+      size = best + 4u;
+      atomicAdd(&s_counts[select], 1ull);
+      atomicAdd(&s_counts[9], (u64)size);
+    } else if (algo == 2) {                // ---- FPC (FPC.cpp:7-88)
+      const u32 kBits[8] = {6, 7, 11, 19, 19, 19, 11, 35};
+      bool prev_zero = false;
+      for (int i = 0; i < L / 4; i++) {
+        const u32 v = (u32)d[4 * i] | ((u32)d[4 * i + 1] << 8) | ((u32)d[4 * i + 2] << 16) | ((u32)d[4 * i + 3] << 24);
+        const u32 p = fpc_prefix(v);
+        size += (p == 0u && prev_zero) ? 0u : kBits[p];
+        prev_zero = p == 0u;
+        atomicAdd(&s_counts[p], 1ull);
+      }
+      atomicAdd(&s_counts[8], (u64)size);
+    } else {                               // ---- BPC (BPC.cpp:20-185)
+      const int n = L / 4, nd = n - 1;
+      long long delta[MPC_MAX_LINE / 4];
+      for (int r = 1; r < n; r++) {
+        const u32 a = (u32)d[4 * r] | ((u32)d[4 * r + 1] << 8) | ((u32)d[4 * r + 2] << 16) | ((u32)d[4 * r + 3] << 24);
+        const u32 b = (u32)d[4 * r - 4] | ((u32)d[4 * r - 3] << 8) | ((u32)d[4 * r - 2] << 16) | ((u32)d[4 * r - 1] << 24);
+        delta[r - 1] = (long long)a - (long long)b;
+      }
+      u32 length = 3 + 4, run = 0, prev = 0;
+      for (int c = 32; c >= 0; c--) {
+        u32 dbp = 0;
+        for (int r = nd - 1; r >= 0; r--) dbp = (dbp << 1) | (u32)((delta[r] >> c) & 1);
+        const u32 dbx = c == 32 ? dbp : (dbp ^ prev);
+        prev = dbp;
+        if (dbx == 0u) { run++; continue; }
+        if (run) {
+          length += run == 1u ? 3u : 7u;
+          atomicAdd(&s_counts[1], 1ull);
+        }
+        run = 0;
+        const u32 ones = (u32)__popc(dbx);
+        int pat;
+        if (dbp == 0u) { length += 5; pat = 2; }
+        else if (dbx == 0x7fffffffu) { length += 5; pat = 6; }
+        else if (ones == 1u) { length += 10; pat = 3; }
+        else if (ones == 2u && (dbx & (dbx >> 1)) != 0u) { length += 10; pat = 4; }
+        else { length += 32; pat = 0; }
+        atomicAdd(&s_counts[pat], 1ull);
+      }
+      if (run) {
+        length += run == 1u ? 3u : 7u;
+        atomicAdd(&s_counts[1], 1ull);
+      }
+      size = length;
+      atomicAdd(&s_counts[7], 33ull);
+      atomicAdd(&s_counts[8], (u64)size);
+    }
+    if (sizes_out) sizes_out[line] = (uint16_t)size;
+    if (sel_out) sel_out[line] = (int8_t)(algo == 1 ? select : 0);
+  }
+  __syncthreads();
+  const int len = algo == 1 ? MPC_BDI_RAW_LEN : (algo == 2 ? MPC_FPC_RAW_LEN : MPC_BPC_RAW_LEN);
+  if ((int)threadIdx.x < len && s_counts[threadIdx.x]) atomicAdd(&gstats[threadIdx.x], s_counts[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
 // measurement helpers
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ u64 splitmix64(u64 x)
@@ -699,7 +819,10 @@ extern "C" hipError_t mpc_launch_bdi(const void *d_lines, u64 n_lines, int L, ui
   case 32: hipLaunchKernelGGL(bdi_kernel<8>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   case 64: hipLaunchKernelGGL(bdi_kernel<16>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   case 128: hipLaunchKernelGGL(bdi_kernel<32>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
-  default: return hipErrorInvalidValue;
+  default:     // any other line size: the loop kernel
+    hipLaunchKernelGGL(baseline_generic_kernel, dim3(grid), dim3(128), 0, stream, 1, static_cast<const uint8_t *>(d_lines), n_lines, L,
+                       d_sizes, d_sel, d_stats);
+    break;
   }
   return hipGetLastError();
 }
@@ -712,7 +835,10 @@ extern "C" hipError_t mpc_launch_fpc(const void *d_lines, u64 n_lines, int L, ui
   case 32: hipLaunchKernelGGL(fpc_kernel<8>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   case 64: hipLaunchKernelGGL(fpc_kernel<16>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   case 128: hipLaunchKernelGGL(fpc_kernel<32>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
-  default: return hipErrorInvalidValue;
+  default:     // any other line size: the loop kernel
+    hipLaunchKernelGGL(baseline_generic_kernel, dim3(grid), dim3(128), 0, stream, 2, static_cast<const uint8_t *>(d_lines), n_lines, L,
+                       d_sizes, d_sel, d_stats);
+    break;
   }
   return hipGetLastError();
 }
@@ -725,7 +851,10 @@ extern "C" hipError_t mpc_launch_bpc(const void *d_lines, u64 n_lines, int L, ui
   case 32: hipLaunchKernelGGL(bpc_kernel<8>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   case 64: hipLaunchKernelGGL(bpc_kernel<16>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
   case 128: hipLaunchKernelGGL(bpc_kernel<32>, dim3(grid), dim3(256), 0, stream, l, n_lines, d_sizes, d_sel, d_stats); break;
-  default: return hipErrorInvalidValue;
+  default:     // any other line size: the loop kernel
+    hipLaunchKernelGGL(baseline_generic_kernel, dim3(grid), dim3(128), 0, stream, 3, static_cast<const uint8_t *>(d_lines), n_lines, L,
+                       d_sizes, d_sel, d_stats);
+    break;
   }
   return hipGetLastError();
 }

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MPC_O_MAX_LINE 256
-#define MPC_O_MAX_MODULES 16
+#define MPC_O_MAX_MODULES 32
 #define MPC_O_MAX_TABLE (8 * MPC_O_MAX_LINE)
 
 /* module kinds (VPC.cpp:125-320) */

@@ -21,7 +21,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MAX_LINE = 256
-MAX_MODULES = 16
+MAX_MODULES = 32
 MAX_TABLE = 8 * MAX_LINE
 
 KIND_ALLZERO, KIND_ALLWORDSAME, KIND_PREDCOMP = 0, 1, 2

@@ -31,10 +31,15 @@ def _check_vpc(mpc, oracle, cfg, lines, expect_path=None):
     # derived doubles equal the reference's running doubles (L is a power of two)
     res = ev.result()
     assert res["comp_ratio"] == o.st.comp_ratio
-    if ev.line_size & (ev.line_size - 1) == 0:
-        for c in range(-1, ev.num_modules):
+    for c in range(-1, ev.num_modules):
+        if ev.line_size & (ev.line_size - 1) == 0:
             assert res["clusters"][c]["mae"] == o.st.mae[c + 1]
             assert res["clusters"][c]["mse"] == o.st.mse[c + 1]
+        else:
+            # the reference adds a ROUNDED (sum r)/L per line to a running double; the integer sums divide once.
+            # The two agree exactly for power-of-two L and to ~1e-15 relative otherwise (deviations).
+            assert res["clusters"][c]["mae"] == pytest.approx(o.st.mae[c + 1], rel=1e-12, abs=0)
+            assert res["clusters"][c]["mse"] == pytest.approx(o.st.mse[c + 1], rel=1e-12, abs=0)
     ev.close()
     return s, sel
 
@@ -202,6 +207,22 @@ def test_vpc_many_modules_large_histogram(mpc, oracle, configs, traces):
     _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:1500], expect_path=mpc.MPC_PATH_VPC_GENERIC)
 
 
+def test_vpc_more_than_sixteen_modules(mpc, oracle, configs, traces):
+    """24 modules (22 prediction modules) at 64-byte lines: above the former limit of 16; both kernels."""
+    L = 64
+    lines = np.concatenate([traces.structured(2400, L, seed=13), traces.mixed(500, L), traces.random_u32(200, L)])
+    mods = [{"name": "AllZero"}, {"name": "AllWordSame"}]
+    for i in range(22):
+        base = [max(j - 1 - (i % 3), 0) if j % 4 > i % 3 else max(4 * (j // 4) - 1, 0) for j in range(L)]
+        mods.append([configs.one_base(L, 0, bool(i & 1)), configs.consecutive_base(L, 0, bool(i & 2)),
+                     configs.diff_base(L, base, [i - 9] * L, 0, bool(i & 1)),
+                     configs.weight_base(L, base, [[1.0, 0.5, 2.0][(i + j) % 2] for j in range(L)], 0, bool(i & 4))][i % 4])
+    enc = [int(x) for x in np.random.default_rng(2).integers(0, 12, len(mods) + 1)]
+    _check_vpc(mpc, oracle, configs.make_config(L, mods, enc), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+    mods[5] = configs.one_base(L, 9, False)
+    _check_vpc(mpc, oracle, configs.make_config(L, mods, enc), lines[:1200], expect_path=mpc.MPC_PATH_VPC_GENERIC)
+
+
 def _random_windowed_config(configs, rng, L):
     """Random fast-path configuration: 1..6 prediction modules of random kinds; windowed base
     tables (base byte in the own or the previous 32-bit word, never ahead of the byte), random
@@ -309,6 +330,30 @@ def test_bdi(mpc, oracle, traces, L):
         ev.reset()
         s, sel = ev.compress_lines(traces.pointers_u64(4096, 128))
         assert (s == 564).all() and (sel == 4).all()
+
+
+@pytest.mark.parametrize("L", [8, 24, 48, 96, 120])
+def test_baselines_any_line_size(mpc, oracle, traces, L):
+    """BDI / FPC / BPC at line sizes other than 32 / 64 / 128 (the reference takes whatever line size the
+    loader reports): the loop kernel, against the oracle."""
+    rng = np.random.default_rng(L)
+    lines = np.concatenate([traces.bdi_stress(2800, 128)[:, :L], traces.structured(2400, 128)[:, :L],
+                            traces.random_u32(300, 128)[:, :L], np.zeros((20, L), np.uint8),
+                            traces.counters_u32(500, 128)[:, :L]])
+    lines = np.ascontiguousarray(lines[rng.permutation(len(lines))])
+    ev, o = mpc.BDI(L), oracle.BdiOracle(L)
+    s_ref, sel_ref = o.compress(lines)
+    s, sel = ev.compress_lines(lines)
+    assert (s == s_ref).all() and (sel == sel_ref).all() and (ev.stats_vector() == o.stats_vector()).all()
+    ev.close()
+    ev, o = mpc.FPC(L), oracle.FpcOracle(L)
+    s, _ = ev.compress_lines(lines)
+    assert (s == o.compress(lines)).all() and (ev.stats_vector() == o.stats_vector()).all()
+    ev.close()
+    ev, o = mpc.BPC(L), oracle.BpcOracle(L)
+    s, _ = ev.compress_lines(lines)
+    assert (s == o.compress(lines)).all() and (ev.stats_vector() == o.stats_vector()).all()
+    ev.close()
 
 
 @pytest.mark.parametrize("L", [32, 64, 128])
