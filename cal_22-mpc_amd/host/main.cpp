@@ -2,10 +2,10 @@
 // flag-for-flag:  compressor -a ALGO -i TRACE [-c CONFIG.json] [-o OUTDIR] [-h]
 // stdout "comp.ratio: <double>", CSV rows appended to OUTDIR/<stem>_results.csv and
 // OUTDIR/<stem>_results_detail.csv.  This build evaluates VPC, BDI, FPC and BPC (the hot path
-// of SURVEY.md section 8) on the MI355X; traces are .npy files or GPGPU-Sim .log
-// files (GLOBAL_ACC_R / GLOBAL_ACC_W requests, reference main.cpp:222-224).  The other
-// algorithm names and the APSim .txt format are recognised and reported as not part
-// of this build.
+// of SURVEY.md section 8) on the MI355X; traces are .npy files, GPGPU-Sim .log files
+// (GLOBAL_ACC_R / GLOBAL_ACC_W requests, reference main.cpp:222-224) or APSim .txt files
+// (32-byte data beats of handshaking channels).  The other algorithm names are recognised
+// and reported as not part of this build.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,8 +16,11 @@
 #include "BDI.h"
 #include "BPC.h"
 #include "FPC.h"
+#include "LoaderAPSim.h"
 #include "LoaderGPGPU.h"
 #include "LoaderNPY.h"
+
+#define REQ_SIZE 32   // line size asked of the APSim loader (reference main.cpp:23)
 #include "VPC.h"
 #include "utils.h"
 
@@ -98,8 +101,7 @@ int main(int argc, char **argv)
   } else if (mpctext::ends_with(tracePath, ".log")) {
     loader = new trace::gpgpusim::LoaderGPGPU(tracePath);
   } else if (mpctext::ends_with(tracePath, ".txt")) {
-    std::cout << "APSim .txt traces are not part of this build (see DESIGN.md, \"Out of scope\")." << std::endl;
-    return 1;
+    loader = new trace::apsim::LoaderGPGPU(tracePath, REQ_SIZE);
   } else {
     std::cerr << "Unsupported extension." << std::endl;
     abort();
@@ -184,7 +186,9 @@ static comp::CompResult *compressLines(comp::Compressor *compressor, trace::Load
     // the reference's loop (main.cpp:208-248): one request object handed back and forth, a .log
     // trace's requests filtered to GLOBAL_ACC_R / GLOBAL_ACC_W (main.cpp:222-224)
     trace::gpgpusim::LoaderGPGPU *gpgpu = dynamic_cast<trace::gpgpusim::LoaderGPGPU *>(loader);
-    trace::MemReq_t *memReq = gpgpu ? new trace::gpgpusim::MemReqGPU_t : new trace::MemReq_t;
+    trace::MemReq_t *memReq = gpgpu ? static_cast<trace::MemReq_t *>(new trace::gpgpusim::MemReqGPU_t)
+                              : dynamic_cast<trace::apsim::LoaderGPGPU *>(loader) ? static_cast<trace::MemReq_t *>(new trace::apsim::MemReqGPU_t)
+                                                                                  : new trace::MemReq_t;
     memReq->Reset();
     while (1) {
       memReq = loader->GetCacheline(memReq);

@@ -292,3 +292,52 @@ def write_gpgpusim_log(path: str, lines: np.ndarray, req_types=None, seed: int =
         f.write(tail)
     return path
 
+
+
+# ---- APSim ".txt" traces (reference src/loader/LoaderGPGPU.cpp:177-228, 469-510) ----------------
+def write_apsim_txt(path: str, beats: np.ndarray, write_trace: bool = False, seed: int = 5, final_newline: bool = True,
+                    idle_rows: bool = True) -> str:
+    """Synthetic APSim traffic file in the layout the reference's loader reads: a header row naming the columns
+    (with "last" columns for a read trace, "strb" for a write trace), then rows
+    cycle,clock,valid0..3,data0..3,ready0..3,last0..3|strb0..3 with 32-byte data beats as 64 hex digits.
+    ``beats`` ([n, 32] uint8) are dealt to random channels of handshaking rows (1-4 per row); rows with clock 0,
+    rows without a valid channel and rows with valid but not ready channels (carrying other data) are mixed in."""
+    beats = np.ascontiguousarray(beats, dtype=np.uint8)
+    assert beats.ndim == 2 and beats.shape[1] == 32
+    rng = np.random.default_rng(seed)
+    tail = "strb" if write_trace else "last"
+    cols = ["Time", "clk"] + [f"valid_{i}" for i in range(4)] + [f"data_{i}" for i in range(4)] + \
+           [f"ready_{i}" for i in range(4)] + [f"{tail}_{i}" for i in range(4)]
+    rows = [",".join(cols)]
+    cycle, i, n = 1000, 0, len(beats)
+
+    def row(clock, valid, ready, data):
+        extra = [format(int(rng.integers(0, 1 << 32)), "08x") if write_trace else str(int(rng.integers(0, 2))) for _ in range(4)]
+        return ",".join([str(cycle), str(clock)] + [str(v) for v in valid] + [bytes(d).hex() for d in data] +
+                        [str(r) for r in ready] + extra)
+    while i < n:
+        cycle += int(rng.integers(1, 9))
+        junk = rng.integers(0, 256, (4, 32), dtype=np.uint8)
+        kind = int(rng.integers(0, 10)) if idle_rows else 9
+        if kind == 0:        # falling clock edge: ignored whatever else it says
+            rows.append(row(0, [1, 1, 1, 1], [1, 1, 1, 1], junk))
+        elif kind == 1:      # nothing valid
+            rows.append(row(1, [0, 0, 0, 0], [int(x) for x in rng.integers(0, 2, 4)], junk))
+        elif kind == 2:      # valid without ready: no handshake
+            v = [int(x) for x in rng.integers(0, 2, 4)]
+            rows.append(row(1, v, [0 if x else 1 for x in v], junk))
+        else:
+            k = min(int(rng.integers(1, 5)), n - i)
+            chans = sorted(rng.permutation(4)[:k].tolist())
+            valid, ready, data = [0] * 4, [0] * 4, junk.copy()
+            for c in chans:
+                valid[c], ready[c] = 1, 1
+                data[c] = beats[i]
+                i += 1
+            for c in range(4):      # other channels: valid or ready alone, never both
+                if c not in chans:
+                    valid[c], ready[c] = [(0, 0), (1, 0), (0, 1)][int(rng.integers(0, 3))]
+            rows.append(row(1, valid, ready, data))
+    with open(path, "w", newline="") as f:
+        f.write("\n".join(rows) + ("\n" if final_newline else ""))
+    return path

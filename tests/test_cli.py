@@ -64,7 +64,7 @@ def test_out_of_scope_algorithms_and_formats(cli, traces, tmp_path):
         r = run([cli, "-a", algo, "-i", p, "-o", str(tmp_path)])
         assert r.returncode == 1 and "not part of this build" in r.stdout
     r = run([cli, "-a", "BDI", "-i", str(d / "t.txt"), "-o", str(tmp_path)])
-    assert r.returncode == 1 and "not part of this build" in r.stdout
+    assert r.returncode == 1 and "Failed to open a file" in r.stdout
     r = run([cli, "-a", "BDI", "-i", str(d / "missing.log"), "-o", str(tmp_path)])
     assert r.returncode == 1 and "Failed to open a file" in r.stdout
     r = run([cli, "-a", "BDI", "-i", str(d / "t.bin"), "-o", str(tmp_path)])
@@ -329,3 +329,43 @@ def test_per_line_drop_in_matches_batch(cli, oracle, configs, traces, tmp_path):
     rp = run([cli, "-a", "VPC", "-i", plog, "-c", cfg_path, "-o", str(op), "--per-line"])
     assert rb.returncode == 0 and rp.returncode == 0 and rb.stdout == rp.stdout
     assert (ob / "probe64_results_detail.csv").read_text() == (op / "probe64_results_detail.csv").read_text()
+
+
+@pytest.mark.gpu
+def test_cli_apsim_txt(cli, oracle, configs, traces, tmp_path):
+    """APSim .txt traffic files through the CLI (reference main.cpp:80-81: 32-byte lines): the data beats of
+    handshaking channels, batch and per-line loop alike.  Expected text from the oracle run on
+    oracle/apsim_txt.py's reading of the same file (parity unpinned: no fixture exists)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import apsim_txt as A
+    ds = tmp_path / "apsim"
+    ds.mkdir()
+    beats = np.concatenate([traces.structured(2400, 32, seed=5), traces.counters_u32(800, 32), traces.random_u32(300, 32),
+                            traces.zeros(50, 32)])
+    beats = beats[np.random.default_rng(4).permutation(len(beats))]
+    p = traces.write_apsim_txt(str(ds / "rd.txt"), beats)
+    kept = A.lines(p, 32)
+    assert len(kept) == len(beats)
+    cfg = configs.probe_config(32)
+    cfg_path = configs.write_config(cfg, str(tmp_path / "probe32.json"))
+    o = oracle.VpcOracle(cfg)
+    o.compress(kept)
+    row, det = vpc_expected_rows(o, "apsim_rd")
+    h1, h2 = vpc_headers(6)
+    for extra, sub in (([], "a"), (["--per-line"], "b")):
+        out = tmp_path / sub
+        out.mkdir()
+        r = run([cli, "-a", "VPC", "-i", p, "-c", cfg_path, "-o", str(out)] + extra)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.strip().split("\n")[-1] == "comp.ratio: " + fmt_double(o.st.comp_ratio)
+        assert (out / "probe32_results.csv").read_text() == h1 + row + "\n"
+        assert (out / "probe32_results_detail.csv").read_text() == h2 + det + "\n"
+    pw = traces.write_apsim_txt(str(ds / "wr.txt"), beats[:1500], write_trace=True, final_newline=False)
+    kept = A.lines(pw, 32)
+    assert 0 < len(kept) < 1500
+    r = run([cli, "-a", "BDI", "-i", pw, "-o", str(tmp_path)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    ob = oracle.BdiOracle(32)
+    ob.compress(kept)
+    assert r.stdout.strip().split("\n")[-1] == "comp.ratio: " + fmt_double(ob.st.comp_ratio)

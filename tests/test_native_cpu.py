@@ -34,7 +34,8 @@ def _fnv(data: bytes) -> int:
 def loader_probe(tmp_path_factory):
     tmp = str(tmp_path_factory.mktemp("native"))
     return _build(tmp, "loader_probe", ["g++", "-std=c++17", *SAN, "-I", HOST, os.path.join(NATIVE, "loader_probe.cpp"),
-                                        os.path.join(HOST, "LoaderNPY.cpp"), os.path.join(HOST, "LoaderGPGPU.cpp")])
+                                        os.path.join(HOST, "LoaderNPY.cpp"), os.path.join(HOST, "LoaderGPGPU.cpp"),
+                                        os.path.join(HOST, "LoaderAPSim.cpp"), os.path.join(HOST, "utils.cpp")])
 
 
 @pytest.mark.parametrize("n,L", [(1, 64), (2, 64), (1000, 32), (777, 128)])
@@ -178,3 +179,43 @@ def test_double_text_matches_fmt_layout(tmp_path):
     assert len(out) == len(vals)
     for v, got in zip(vals, out):
         assert got == known.get(v, fmt_like(v)), (v, got)
+
+
+@pytest.mark.parametrize("write_trace,line_size", [(False, 32), (True, 32), (False, 64)])
+def test_loader_apsim_txt_matches_restatement(loader_probe, traces, tmp_path, write_trace, line_size):
+    """trace::apsim::LoaderGPGPU (host mirror) on synthetic APSim .txt traffic files against the Python
+    restatement of the reference's reader (oracle/apsim_txt.py): handshake filter, channel order, 32-byte
+    beats and 64-byte two-beat lines, a last row without a newline dropped, read and write headers."""
+    sys.path.insert(0, ROOT)
+    from oracle import apsim_txt as A
+    beats = np.concatenate([traces.structured(700, 32, seed=8), traces.random_u32(200, 32), traces.zeros(30, 32)])
+    beats = beats[np.random.default_rng(1).permutation(len(beats))]
+    for final_newline in (True, False):
+        p = traces.write_apsim_txt(str(tmp_path / f"t{int(final_newline)}.txt"), beats, write_trace=write_trace,
+                                   final_newline=final_newline)
+        want = A.lines(p, line_size)
+        if line_size == 32:
+            # every beat but (without the final newline) those of the last row comes back, in order
+            assert len(want) <= len(beats) and (want == beats[: len(want)]).all()
+            assert (len(want) == len(beats)) == final_newline
+        for mode in (["line"], ["batch", "7", str(line_size)], ["batch", "100000", str(line_size)]):
+            args = mode if mode[0] == "batch" else ["line", "0", str(line_size)]
+            r = subprocess.run([loader_probe, p] + args, capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+            out = r.stdout.strip().split("\n")
+            assert out[0] == f"lines {len(want)} line_size {line_size}"
+            assert out[1] == f"delivered {len(want)} hash {_fnv(want.tobytes())}"
+
+
+def test_loader_apsim_txt_rejects_bad_files(loader_probe, traces, tmp_path):
+    (tmp_path / "nohdr.txt").write_text("Time,clk,a,b\n1,1\n")
+    (tmp_path / "empty.txt").write_text("")
+    good = traces.write_apsim_txt(str(tmp_path / "g.txt"), traces.random_u32(5, 32))
+    text = open(good).read().split("\n")
+    (tmp_path / "short.txt").write_text("\n".join(text[:2]) + "\n1,1,1,0\n")
+    (tmp_path / "badhex.txt").write_text(text[0] + "\n" + text[1].replace(text[1].split(",")[6], "zz" * 32) + "\n")
+    for name, msg in (("nohdr.txt", "header of the GPU traffic file"), ("empty.txt", "header of the GPU traffic file"),
+                      ("missing.txt", "Failed to open"), ("short.txt", "row of the GPU traffic file"),
+                      ("badhex.txt", "row of the GPU traffic file")):
+        r = subprocess.run([loader_probe, str(tmp_path / name), "line"], capture_output=True, text=True)
+        assert r.returncode == 1 and msg in r.stdout, (name, r.stdout, r.stderr[-500:])
