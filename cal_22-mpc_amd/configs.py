@@ -137,6 +137,48 @@ def element_config(line_size: int, element_bytes: int, encoding_bits: Optional[L
     return make_config(L, mods, encoding_bits)
 
 
+# ---- per-datatype prediction models (the five models of the paper's overview figure, MPC.PNG) ----
+# The reference ships no configuration files, so the TABLES below are this repository's: one prediction
+# module per data type in the figure -- Bool/INT8, INT16, INT32/64, FP32, FP64 -- each predicting a byte
+# from the same byte of the previous element (DiffBase), the IEEE formats with the exponent bytes at full
+# weight and mantissa bytes at half weight (WeightBase) or through the byte-plane shuffle
+# (ConsecutiveBase, 32-bit words).  Every one of them runs on the fast kernel path.
+DTYPE_BYTES = {"bool": 1, "int8": 1, "int16": 2, "int32": 4, "int64": 8, "fp16": 2, "fp32": 4, "fp64": 8}
+
+
+def datatype_module(line_size: int, dtype: str) -> Dict:
+    """The prediction module for one data type (see above)."""
+    L = line_size
+    if dtype not in DTYPE_BYTES:
+        raise ValueError(f"dtype must be one of {sorted(DTYPE_BYTES)}")
+    eb = DTYPE_BYTES[dtype]
+    base = [max(i - eb, 0) for i in range(L)]
+    if dtype in ("bool", "int8", "int16", "int32", "int64"):
+        # previous element, same byte; consecutive XOR turns small signed differences into short codes
+        return diff_base(L, base, [0] * L, 0, True)
+    if dtype == "fp32":
+        return consecutive_base(L, 0, True)
+    # fp16 / fp64: little-endian elements, sign + exponent in the top byte(s): full weight there, half below
+    top = 1 if dtype == "fp16" else 2
+    weight = [1.0 if (i % eb) >= eb - top else 0.5 for i in range(L)]
+    return weight_base(L, base, weight, 0, True)
+
+
+def datatype_config(line_size: int, dtype: str, encoding_bits: Optional[List[int]] = None) -> Dict:
+    """AllZero, AllWordSame and the prediction module of one data type."""
+    return make_config(line_size, [{"name": "AllZero"}, {"name": "AllWordSame"}, datatype_module(line_size, dtype)],
+                       encoding_bits)
+
+
+def mpc_config(line_size: int = 32, encoding_bits: Optional[List[int]] = None) -> Dict:
+    """The seven-module shape of the paper's overview figure (MPC.PNG; 32-byte blocks there): all-zero and
+    all-words-same tests and the five prediction models Bool/INT8, INT16, INT32/64, FP32, FP64."""
+    L = line_size
+    mods = [{"name": "AllZero"}, {"name": "AllWordSame"}, datatype_module(L, "int8"), datatype_module(L, "int16"),
+            datatype_module(L, "int32"), datatype_module(L, "fp32"), datatype_module(L, "fp64")]
+    return make_config(L, mods, encoding_bits)
+
+
 def write_config(cfg: Dict, path: str) -> str:
     with open(path, "w") as f:
         json.dump(cfg, f)
@@ -144,17 +186,21 @@ def write_config(cfg: Dict, path: str) -> str:
 
 
 if __name__ == "__main__":
-    # python cal_22-mpc_amd/configs.py --line 64 --element 8 -o cfg.json
+    # python cal_22-mpc_amd/configs.py --line 64 --model mpc -o cfg.json
     import argparse
     ap = argparse.ArgumentParser(description="write a VPC configuration for the `compressor -c` option")
     ap.add_argument("--line", type=int, default=64, help="line size in bytes (32, 64 or 128 for the fast kernel)")
-    ap.add_argument("--element", type=int, default=4, choices=[1, 2, 4, 8], help="element size in bytes")
+    ap.add_argument("--model", default="probe", choices=["probe", "mpc"] + sorted(DTYPE_BYTES),
+                    help="probe: the 6-module probe set for --element-byte elements; mpc: the paper figure's five "
+                         "data-type models; a data type: that type's model alone")
+    ap.add_argument("--element", type=int, default=4, choices=[1, 2, 4, 8], help="element size in bytes (probe model)")
     ap.add_argument("-o", "--output", default="-")
     a = ap.parse_args()
-    text = json.dumps(element_config(a.line, a.element))
+    cfg = element_config(a.line, a.element) if a.model == "probe" else mpc_config(a.line) if a.model == "mpc" \
+        else datatype_config(a.line, a.model)
+    text = json.dumps(cfg)
     if a.output == "-":
         print(text)
     else:
         with open(a.output, "w") as f:
             f.write(text)
-

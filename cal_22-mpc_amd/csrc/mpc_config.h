@@ -195,10 +195,12 @@ struct VpcPlan {
   std::vector<uint8_t> gtab;       // generic-path byte tables
 };
 
+// plane-major identity scan table, possibly truncated (TableSize < 8 L: only the leading bits are scanned,
+// the remaining cells of the scanned array stay zero, ScanModule.cpp:13-19)
 inline bool is_plane_major_scan(const Module &m, int L)
 {
-  if (m.table_size != 8 * L) return false;
-  for (int i = 0; i < 8 * L; i++)
+  if (m.table_size > 8 * L) return false;
+  for (int i = 0; i < m.table_size; i++)
     if (m.rows[(size_t)i] != i / L || m.cols[(size_t)i] != i % L) return false;
   return true;
 }
@@ -255,8 +257,12 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     const Module &m = cfg.modules[(size_t)(cfg.start + q)];
     MpcFastModule &f = P.fm[q];
     const std::string tag = "module " + std::to_string(cfg.start + q) + ": ";
-    if (m.root != 0) { no(tag + "RootIndex != 0"); break; }
-    if (!is_plane_major_scan(m, L)) { no(tag + "scan table is not the plane-major identity"); break; }
+    if (!is_plane_major_scan(m, L)) { no(tag + "scan table is not a (truncated) plane-major identity"); break; }
+    if (m.table_size != cfg.modules[(size_t)cfg.start].table_size) { no(tag + "scan tables of different sizes"); break; }
+    // any root for OneBase / DiffBase / WeightBase: the residue array is the natural one with bytes 0..root
+    // rotated by one position (ResidueModule.cpp:24-39); run-time module loop only
+    f.root = m.root;
+    if (m.root != 0 || m.table_size != 8 * L) P.runtime_only = 1;
     f.cx = m.consecutive_xor ? 1 : 0;
     f.tab_off = (int32_t)plan.tab.size();
     if (m.pred_kind == PRED_ONEBASE) { f.kind = MPC_FK_ONEBASE; continue; }
@@ -266,11 +272,11 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     // (BaseIndexTable[i] = i - 8), which the lane-per-line kernel serves straight from registers
     std::vector<uint32_t> sel((size_t)W, 0), c1((size_t)W, 0), c2((size_t)W, 0);
     int shifts[2] = {0, 0}, nshift = 0;
-    bool stride2 = L >= 16;
+    bool stride2 = L >= 16 && m.root == 0;
     for (int i = 8; i < L; i++) stride2 = stride2 && m.base[(size_t)i] == i - 8;
     for (int i = 0; i < L && plan.fast; i++) {
       const int w = i / 4, k = i % 4;
-      if (i == 0) { sel[0] |= 0x0cu; continue; }  // root: predicted byte forced to 0
+      if (i == m.root) { sel[(size_t)w] |= 0x0cu << (8 * k); continue; }  // root: predicted byte forced to 0
       const int b = m.base[(size_t)i];
       int s;
       if (stride2 && w >= 2) {
@@ -338,6 +344,24 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
       for (size_t w = 4; w < sel.size(); w++)
         if (c1[w] != c1[2 + (w & 1)] || c2[w] != c2[2 + (w & 1)]) { no(tag + "BaseIndexTable i-8 with constants that do not repeat every 8 bytes"); break; }
       if (!plan.fast) break;
+    }
+  }
+  P.trunc_off = -1;
+  if (plan.fast && cfg.n_pred > 0 && cfg.modules[(size_t)cfg.start].table_size != 8 * L) {
+    // scanned bit i = plane i / L (0 = MSB), byte i % L, for i < TableSize: per residue byte the mask of its scanned bits
+    const int ts = cfg.modules[(size_t)cfg.start].table_size;
+    while (plan.tab.size() % 4) plan.tab.push_back(0);
+    P.trunc_off = (int32_t)plan.tab.size();
+    for (int w = 0; w < W; w++) {
+      uint32_t word = 0;
+      for (int k = 0; k < 4; k++) {
+        const int col = 4 * w + k;
+        uint32_t bm = 0;
+        for (int p = 0; p < 8; p++)
+          if (p * L + col < ts) bm |= 0x80u >> p;
+        word |= bm << (8 * k);
+      }
+      plan.tab.push_back(word);
     }
   }
   while (plan.tab.size() % 4) plan.tab.push_back(0);

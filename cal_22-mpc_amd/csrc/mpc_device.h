@@ -25,6 +25,7 @@ struct MpcFastModule {
   int32_t ls1, rs1;   /* WEIGHT: first shift class  ((b << ls1) >> rs1) & c1 */
   int32_t ls2, rs2;   /* WEIGHT: second shift class ((b << ls2) >> rs2) & c2 */
   int32_t tab_off;    /* DIFF/WEIGHT: dword offset of {sel, c1, c2, c1 & 0x7f.., c1 & 0x80..}[L/4 each] in tab */
+  int32_t root;       /* RootIndex (0 on the unrolled kernels; any position for ONEBASE / DIFF / WEIGHT* on the run-time loop) */
   int32_t prev_word;  /* DIFF/WEIGHT periodic tables.  1: every base byte of words 1.. is the same byte of the
                          previous word (BaseIndexTable[i] = i - 4) and the table entries of words 1.. are
                          identical: no v_perm_b32, two table entries instead of L/4.  2: the same two words
@@ -52,8 +53,11 @@ struct MpcVpcParams {
   int32_t start;        /* module index of the first PredComp module (1 or 2) */
   int32_t has_aws;      /* module 1 is AllWordSame */
   int32_t hist_bins;    /* bins per cluster */
-  int32_t reserved0;
+  int32_t runtime_only; /* fast path, but only through the run-time module loop: a RootIndex != 0 or a truncated scan table */
   int32_t tab_words;    /* number of dwords in tab */
+  int32_t trunc_off;    /* truncated plane-major scan table (TableSize < 8 L, the same for every module): dword offset in
+                           tab of L/4 mask words (the bits of the XORed residue bytes that are scanned); -1: full table */
+  int32_t reserved1;
   int32_t enc_bits[MPC_MAX_MODULES + 1];  /* index cluster+1 */
   struct MpcFastModule fm[MPC_MAX_PRED];
   struct MpcGenModule gm[MPC_MAX_PRED];

@@ -172,14 +172,24 @@ __device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &
 // non-zero row of the XORed planes equals that of the raw residue planes (DESIGN.md
 // "Selector on raw residues"), so the selector works on r directly.
 template <int W>
-__device__ __forceinline__ u32 lane_leading_zero_rows(const u32 (&r)[W])
+__device__ __forceinline__ u32 lane_leading_zero_rows(const u32 (&r)[W], const u32 *__restrict__ scan_mask = nullptr)
 {
   constexpr int NG = W / 4;
   u32 S[NG], G = 0;
+  if (scan_mask) {
+    // truncated scan table (run-time loop only): bits that are not scanned do not count
 #pragma unroll
-  for (int j = 0; j < NG; j++) {
-    S[j] = r[4 * j] | r[4 * j + 1] | r[4 * j + 2] | r[4 * j + 3];
-    G |= S[j];
+    for (int j = 0; j < NG; j++) {
+      S[j] = (r[4 * j] & scan_mask[4 * j]) | (r[4 * j + 1] & scan_mask[4 * j + 1]) | (r[4 * j + 2] & scan_mask[4 * j + 2]) |
+             (r[4 * j + 3] & scan_mask[4 * j + 3]);
+      G |= S[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NG; j++) {
+      S[j] = r[4 * j] | r[4 * j + 1] | r[4 * j + 2] | r[4 * j + 3];
+      G |= S[j];
+    }
   }
   const u32 p = (u32)__clz((int)fold8(G)) - 24u;     // first non-zero plane (0 = MSB); 8 if G == 0
   const u32 B = H80 >> (p & 7u);                      // that plane's bit in every byte
@@ -299,10 +309,27 @@ __device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &
   }
 }
 
-// run-time module sequence (configurations whose sequence has no instantiation): every module
-// in order, no prefilter; the selector starts from z = 0 (VPC.cpp:377-395)
+// word `idx` (wave-uniform) of the line
 template <int W>
-__device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcParams &P, LaneBest<W> &best)
+__device__ __forceinline__ u32 lane_word_at(const u32 (&x)[W], int idx)
+{
+  u32 w = x[0];
+#pragma unroll
+  for (int e = 1; e < W; e++) w = (e == idx) ? x[e] : w;
+  return w;
+}
+
+// run-time module sequence (configurations whose sequence has no instantiation, a RootIndex other
+// than 0, a truncated scan table): every module in order, no prefilter; the selector starts from
+// z = 0 (VPC.cpp:377-395).
+//
+// RootIndex != 0 (OneBase / DiffBase / WeightBase): the predictors work on the natural byte
+// positions -- the tables force the predicted byte at the root position to 0, so the natural
+// residue holds the raw root there -- and ResidueModule.cpp:24-39 then moves the root to the front:
+// bytes 0..root of the natural residue rotate by one position, the rest stays.
+template <int W>
+__device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcParams &P, LaneBest<W> &best,
+                                                 const u32 *__restrict__ scan_mask)
 {
   best.z = 0;
   best.q = -1;
@@ -315,7 +342,19 @@ __device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcP
     const MpcFastModule fm = P.fm[q];
     u32 r[W], root_r;
     switch (fm.kind) {
-    case MPC_FK_ONEBASE: lane_residue<W, MPC_FK_ONEBASE>(c, fm, P.tab, r, root_r); break;
+    case MPC_FK_ONEBASE:
+      if (fm.root == 0) {
+        lane_residue<W, MPC_FK_ONEBASE>(c, fm, P.tab, r, root_r);
+      } else {
+        const int rw = fm.root >> 2, rk = fm.root & 3;
+        const u32 xw = lane_word_at<W>(c.x, rw);
+        const u32 rb = ((xw >> (8 * rk)) & 0xffu) * 0x01010101u;     // line[root] in every byte
+        const u32 here = 0xffu << (8 * rk);
+#pragma unroll
+        for (int e = 0; e < W; e++) r[e] = bsub(c.x[e], e == rw ? (rb & ~here) : rb);   // predicted 0 at the root: raw root
+        root_r = 0;
+      }
+      break;
     case MPC_FK_CONSEC: lane_residue<W, MPC_FK_CONSEC>(c, fm, P.tab, r, root_r); break;
     case MPC_FK_DIFF:
       if (fm.prev_word == 2) lane_residue<W, MPC_FK_DIFF | LK_PW2>(c, fm, P.tab, r, root_r);
@@ -330,7 +369,21 @@ __device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcP
       else lane_residue<W, MPC_FK_WEIGHT2>(c, fm, P.tab, r, root_r);
       break;
     }
-    const u32 z = lane_leading_zero_rows<W>(r);
+    if (fm.root != 0) {
+      // root to the front: residue[0] = natural[root], residue[j] = natural[j - 1] for 1 <= j <= root
+      const int rw = fm.root >> 2, rk = fm.root & 3;
+      const u32 rootraw = (lane_word_at<W>(r, rw) >> (8 * rk)) & 0xffu;
+      u32 prev = rootraw << 24;              // what enters byte 0 of word 0
+#pragma unroll
+      for (int e = 0; e < W; e++) {
+        const u32 sh = alignbyte(r[e], prev, 3);                     // the natural bytes one position up
+        const int nb = fm.root + 1 - 4 * e;                          // bytes of this word at positions <= root
+        const u32 m = nb >= 4 ? ~0u : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+        prev = r[e];
+        r[e] = mask_sel(m, sh, r[e]);
+      }
+    }
+    const u32 z = lane_leading_zero_rows<W>(r, scan_mask);
     const bool take = best.z <= z;     // ties go to the later module (VPC.cpp:389)
     best.z = take ? z : best.z;
     best.q = take ? q : best.q;
@@ -586,6 +639,8 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
   u32 size = is_zero ? E.enc_zero : E.enc_same;
   u32 sum_r = 0, sum_r2 = 0;        // residue statistics of this line (VPC.cpp:417-443)
 
+  // truncated scan table (run-time loop only): per residue word the bits that are scanned
+  const u32 *scan_mask = (NPT == 0 && P.trunc_off >= 0) ? P.tab + P.trunc_off : nullptr;
   if (need_mask) {     // wave-uniform: some line needs the prediction modules
     c.b0 = c.x[0] & 0xffu;
     c.rootb = perm(c.x[0], c.x[0], 0u);
@@ -604,7 +659,7 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
       if (keep_bits == 0) lane_last<W, NPT, 0, KINDS...>(c, P, best);
       else lane_seq<W, NPT, 0, KINDS...>(c, P, keep_bits, best, false);
     } else {
-      lane_seq_runtime<W>(c, P, best);
+      lane_seq_runtime<W>(c, P, best, scan_mask);
     }
     // without any prediction module the empty scanned array encodes to 0 bits and the line is
     // reported uncompressed at that size (VPC.cpp:397-407 with an empty maxScanned)
@@ -627,6 +682,10 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
         const u32 f = ((best.r[e] >> 1) & cx7) | ((a - (a >> 7)) & ncx);
         t[e] = best.r[e] ^ (e == 0 ? (f & 0xffffff00u) : f);
       }
+    }
+    if (NPT == 0 && scan_mask) {
+#pragma unroll
+      for (int e = 0; e < W; e++) t[e] &= scan_mask[e];
     }
     // The certificate pays where it closes every line of the group (incompressible data); where the
     // previous group of this wave still had compressible lines it is skipped and the encoder runs
@@ -781,7 +840,7 @@ bool lane_seq_matches(const MpcVpcParams *P)
 {
   constexpr int n = sizeof...(KINDS);
   const int kinds[n > 0 ? n : 1] = {KINDS...};
-  if (P->n_pred != n || n == 0) return false;
+  if (P->n_pred != n || n == 0 || P->runtime_only) return false;
   for (int q = 0; q < n; q++) {
     // a periodic-table instantiation (LK_PW / LK_PW2) needs its flag; the plain one runs any table
     // that has a byte gather, i.e. all but the two-words-back ones

@@ -54,10 +54,15 @@ def test_custom_encoding_bits_and_generic_classification(mpc, configs):
     cfg = configs.probe_config(64, encoding_bits=[2, 1, 3, 4, 4, 5, 5])
     d = mpc.describe_config(cfg)
     assert d["enc_bits"] == [2, 1, 3, 4, 4, 5, 5] and d["hist_bins"] == 512 + 5 + 1
-    # non-zero root -> generic kernel
+    # non-zero root / truncated plane-major table -> still the fast kernel, through its run-time module loop
     cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, root=7)])
     d = mpc.describe_config(cfg)
-    assert d["rc"] == 0 and d["path"] == "generic" and "RootIndex" in d["why_generic"]
+    assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "run-time loop"
+    ts = 300
+    cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, scan={"TableSize": ts, "Rows": [i // 64 for i in range(ts)],
+                                                                                "Cols": [i % 64 for i in range(ts)]})])
+    d = mpc.describe_config(cfg)
+    assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "run-time loop"
     # permuted scan table -> generic kernel
     scan = configs.plane_major_scan(64)
     scan["Rows"][0], scan["Rows"][100] = scan["Rows"][100], scan["Rows"][0]
@@ -160,3 +165,17 @@ def test_npy_header_malformed_is_an_error_code(mpc, tmp_path):
         assert rc < 0, (i, h, rc)
     ok = write("ok.npy", b"{'descr': '|u1', 'fortran_order': False, 'shape': (3, 64), }" + b" " * 10 + b"\n")
     assert mpc.lib().mpc_npy_shape(ok.encode(), C.byref(rows), C.byref(cols)) == 0 and (rows.value, cols.value) == (3, 64)
+
+
+def test_datatype_model_configs_are_fast_path(mpc, configs, oracle):
+    """The per-datatype models of the authoring tool (the five prediction models of the paper's overview
+    figure and each data type alone) parse, are accepted by the oracle and map to the fast kernel."""
+    for L in (32, 64, 128):
+        for dt in configs.DTYPE_BYTES:
+            cfg = configs.datatype_config(L, dt)
+            d = mpc.describe_config(cfg)
+            assert d["rc"] == 0 and d["path"] == "fast", (L, dt, d)
+            oracle.VpcOracle(cfg)
+        d = mpc.describe_config(configs.mpc_config(L))
+        assert d["rc"] == 0 and d["path"] == "fast" and d["M"] == 7, (L, d)
+        oracle.VpcOracle(configs.mpc_config(L))

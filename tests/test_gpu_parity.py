@@ -189,6 +189,65 @@ def test_vpc_element_configs(mpc, oracle, configs, traces, element):
     _check_vpc(mpc, oracle, configs.element_config(L, element), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
 
 
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_vpc_datatype_model_configs(mpc, oracle, configs, traces, L):
+    """The authoring tool's per-datatype models (configs.datatype_config / mpc_config) on the fast kernel,
+    against the oracle, on traces of the matching element types."""
+    rng = np.random.default_rng(L)
+    n = 1500
+
+    def elems(dtype, gen):
+        return np.ascontiguousarray(gen.astype(dtype)).view(np.uint8).reshape(n, L)
+    per = L // 8
+    typed = np.concatenate([
+        elems("<i2", (rng.integers(-300, 300, (n, 1)) + np.cumsum(rng.integers(-3, 4, (n, L // 2)), axis=1))),
+        elems("<i8", (rng.integers(0, 1 << 40, (n, 1)) + np.cumsum(rng.integers(0, 9, (n, per)), axis=1))),
+        elems("<f8", np.cumsum(rng.normal(size=(n, per)), axis=1) * 1e-3 + 1.0),
+        elems("<f2", np.cumsum(rng.normal(size=(n, L // 2)), axis=1) * 0.01 + 2.0),
+        (rng.integers(0, 2, (n, L)) * rng.integers(0, 2, (n, 1))).astype(np.uint8),
+    ])
+    lines = np.concatenate([typed, traces.structured(2400, L, seed=5), traces.mixed(600, L), traces.random_u32(200, L),
+                            traces.zeros(20, L), traces.word_same(20, L)])
+    lines = lines[rng.permutation(len(lines))]
+    for dt in configs.DTYPE_BYTES:
+        _check_vpc(mpc, oracle, configs.datatype_config(L, dt), lines[:3000], expect_path=mpc.MPC_PATH_VPC_FAST)
+    s, sel = _check_vpc(mpc, oracle, configs.mpc_config(L), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+    assert len(set(sel.tolist())) >= 6          # the five models (and the early-outs) are all chosen somewhere
+
+
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_vpc_fast_path_nonzero_root_and_truncated_scan(mpc, oracle, configs, traces, L):
+    """Layouts beyond RootIndex 0 / full plane-major tables that stay on the fast kernel (run-time module loop):
+    any RootIndex for OneBase / DiffBase / WeightBase (the residue array is rotated root-first,
+    ResidueModule.cpp:24-39) and truncated plane-major scan tables (TableSize < 8 L, the rest of the scanned
+    array stays zero, ScanModule.cpp:13-19).  Against the oracle, whose scan stage is pinned by oracle/_ref."""
+    rng = np.random.default_rng(100 + L)
+    lines = np.concatenate([traces.structured(4000, L, seed=17), traces.mixed(800, L), traces.random_u32(300, L),
+                            traces.counters_u32(500, L), traces.zeros(20, L), traces.word_same(20, L)])
+    lines = lines[rng.permutation(len(lines))]
+    az, aws = {"name": "AllZero"}, {"name": "AllWordSame"}
+
+    def trunc(ts):
+        return {"TableSize": ts, "Rows": [i // L for i in range(ts)], "Cols": [i % L for i in range(ts)]}
+    prev1 = [max(i - 1, 0) for i in range(L)]
+    prev4 = [max(i - 4, 0) for i in range(L)]
+    diff = [(-2 + (i % 5)) for i in range(L)]
+    w2 = [[1.0, 0.5][i % 2] for i in range(L)]
+    for root in (1, 3, 4, 7, L // 2 + 1, L - 1):
+        mods = [az, aws, configs.one_base(L, root, True), configs.diff_base(L, prev1, diff, root, False),
+                configs.weight_base(L, prev4, w2, root, True), configs.one_base(L, 0, False)]
+        _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:3000], expect_path=mpc.MPC_PATH_VPC_FAST)
+    for ts in (8 * L - 24, 6 * L, 4 * L + 7, L, 16, 0):
+        mods = [az, aws, configs.one_base(L, 0, True, trunc(ts)), configs.consecutive_base(L, 0, False, trunc(ts)),
+                configs.diff_base(L, prev4, diff, 0, True, trunc(ts)), configs.weight_base(L, prev4, w2, 0, True, trunc(ts))]
+        _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:3000], expect_path=mpc.MPC_PATH_VPC_FAST)
+    # both at once; and tables of different sizes have no fast form
+    mods = [az, configs.diff_base(L, prev1, diff, 5, True, trunc(5 * L)), configs.weight_base(L, prev4, w2, 2, False, trunc(5 * L))]
+    _check_vpc(mpc, oracle, configs.make_config(L, mods), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+    mods = [az, configs.one_base(L, 0, True, trunc(5 * L)), configs.one_base(L, 0, False, trunc(6 * L))]
+    _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:1500], expect_path=mpc.MPC_PATH_VPC_GENERIC)
+
+
 def test_vpc_many_modules_large_histogram(mpc, oracle, configs, traces):
     """16 modules at 128-byte lines: 17 clusters x 1030 bins = 70 KB of LDS histogram, more than a
     kernel's default 64 KiB (fast kernel with the run-time module loop, and the generic kernel)."""
@@ -203,7 +262,8 @@ def test_vpc_many_modules_large_histogram(mpc, oracle, configs, traces):
                                       [i] * L, 0, bool(i & 1)))
     cfg = configs.make_config(L, mods)
     _check_vpc(mpc, oracle, cfg, lines, expect_path=mpc.MPC_PATH_VPC_FAST)
-    mods[2] = configs.one_base(L, 5, True)            # a non-zero root sends the configuration to the generic kernel
+    perm = [int(x) for x in np.random.default_rng(1).permutation(8 * L)]   # a permuted scan table has no fast form
+    mods[2] = configs.one_base(L, 0, True, {"TableSize": 8 * L, "Rows": [p // L for p in perm], "Cols": [p % L for p in perm]})
     _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:1500], expect_path=mpc.MPC_PATH_VPC_GENERIC)
 
 
@@ -219,7 +279,8 @@ def test_vpc_more_than_sixteen_modules(mpc, oracle, configs, traces):
                      configs.weight_base(L, base, [[1.0, 0.5, 2.0][(i + j) % 2] for j in range(L)], 0, bool(i & 4))][i % 4])
     enc = [int(x) for x in np.random.default_rng(2).integers(0, 12, len(mods) + 1)]
     _check_vpc(mpc, oracle, configs.make_config(L, mods, enc), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
-    mods[5] = configs.one_base(L, 9, False)
+    perm = [int(x) for x in np.random.default_rng(1).permutation(8 * L)]
+    mods[5] = configs.one_base(L, 9, False, {"TableSize": 8 * L, "Rows": [p // L for p in perm], "Cols": [p % L for p in perm]})
     _check_vpc(mpc, oracle, configs.make_config(L, mods, enc), lines[:1200], expect_path=mpc.MPC_PATH_VPC_GENERIC)
 
 
