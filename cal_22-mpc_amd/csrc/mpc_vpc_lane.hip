@@ -114,8 +114,8 @@ __device__ __forceinline__ u32 window_residue(const Lane<W> &c, int e, const u32
 }
 
 // Residue bytes (root first == natural order for RootIndex 0) of one module;
-// root_r = the residue GetMAE / GetMSE see at the root position.
-template <int W, int KIND>
+// root_r = the residue GetMAE / GetMSE see at the root position.  NR: only words 0..NR-1.
+template <int W, int KIND, int NR = W>
 __device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModule &fm, const u32 *__restrict__ tab,
                                              u32 (&r)[W], u32 &root_r)
 {
@@ -124,22 +124,22 @@ __device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModu
     // predicted = line[0] everywhere; position 0 of the residue array is the raw root
     r[0] = bsub(c.x[0], c.rootb & 0xffffff00u);
 #pragma unroll
-    for (int e = 1; e < W; e++) r[e] = bsub(c.x[e], c.rootb);
+    for (int e = 1; e < NR; e++) r[e] = bsub(c.x[e], c.rootb);
   } else if constexpr (lk_base(KIND) == MPC_FK_CONSEC) {
     // predicted[i] = inp[i - 1]; predicted byte 0 := 0 keeps the raw root at position 0
-    u32 in[W];
+    u32 in[NR];
 #pragma unroll
-    for (int j = 0; j < W; j++) in[j] = shuffled_word<W>(c.x, j);
+    for (int j = 0; j < NR; j++) in[j] = shuffled_word<W>(c.x, j);
     r[0] = bsub(c.x[0], in[0] << 8);
 #pragma unroll
-    for (int e = 1; e < W; e++) r[e] = bsub(c.x[e], alignbyte(in[e], in[e - 1], 3));
+    for (int e = 1; e < NR; e++) r[e] = bsub(c.x[e], alignbyte(in[e], in[e - 1], 3));
     // predicted[root] = inp[0] = byte 3 of word 0 (PredictorModule.cpp:159-164)
     root_r = (c.b0 - (c.x[0] >> 24)) & 0xffu;
   } else {
     // windowed tables; they force the predicted root byte to 0, so residue[0] = raw root
     const u32 *t = tab + fm.tab_off;
 #pragma unroll
-    for (int e = 0; e < W; e++) r[e] = window_residue<W, KIND>(c, e, t, fm);
+    for (int e = 0; e < NR; e++) r[e] = window_residue<W, KIND>(c, e, t, fm);
   }
 }
 
@@ -313,24 +313,83 @@ __device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &
 template <int W>
 __device__ __forceinline__ u32 lane_word_at(const u32 (&x)[W], int idx)
 {
-  u32 w = x[0];
+  // OR of masked words: a select chain here is turned into an indexed read of a copy of x[] in scratch memory
+  u32 w = 0;
 #pragma unroll
-  for (int e = 1; e < W; e++) w = (e == idx) ? x[e] : w;
+  for (int e = 0; e < W; e++) w = and_or(x[e], 0u - (u32)(e == idx), w);
   return w;
 }
 
 // run-time module sequence (configurations whose sequence has no instantiation, a RootIndex other
-// than 0, a truncated scan table): every module in order, no prefilter; the selector starts from
-// z = 0 (VPC.cpp:377-395).
+// than 0, a truncated scan table).
+//
+// Order.  The last module is evaluated first, the others follow in DESCENDING order and replace the
+// winner only with strictly more leading zero rows -- the choice of the reference's ascending loop
+// with `<=` (ties go to the later module, VPC.cpp:377-395).  Before a module is evaluated in full its
+// residue words 0..3 (column group 0) give an upper bound of its leading zero rows: a bit in plane p
+// of group 0 means at most (L/16) * p of them.  When that cannot beat the winner so far on any line of
+// the group the module is skipped (on incompressible data: every module but the last).
 //
 // RootIndex != 0 (OneBase / DiffBase / WeightBase): the predictors work on the natural byte
 // positions -- the tables force the predicted byte at the root position to 0, so the natural
 // residue holds the raw root there -- and ResidueModule.cpp:24-39 then moves the root to the front:
 // bytes 0..root of the natural residue rotate by one position, the rest stays.
+template <int W, int NR>
+__device__ __forceinline__ void lane_residue_rt(const Lane<W> &c, const MpcVpcParams &P, const MpcFastModule &fm, u32 (&r)[W],
+                                                u32 &root_r)
+{
+  switch (fm.kind) {
+  case MPC_FK_ONEBASE:
+    if (fm.root == 0) {
+      lane_residue<W, MPC_FK_ONEBASE, NR>(c, fm, P.tab, r, root_r);
+    } else {
+      const int rw = fm.root >> 2, rk = fm.root & 3;
+      const u32 xw = lane_word_at<W>(c.x, rw);
+      const u32 rb = ((xw >> (8 * rk)) & 0xffu) * 0x01010101u;     // line[root] in every byte
+      const u32 here = 0xffu << (8 * rk);
+#pragma unroll
+      for (int e = 0; e < NR; e++) r[e] = bsub(c.x[e], e == rw ? (rb & ~here) : rb);   // predicted 0 at the root: raw root
+      root_r = 0;
+    }
+    break;
+  case MPC_FK_CONSEC: lane_residue<W, MPC_FK_CONSEC, NR>(c, fm, P.tab, r, root_r); break;
+  case MPC_FK_DIFF:
+    if (fm.prev_word == 2) lane_residue<W, MPC_FK_DIFF | LK_PW2, NR>(c, fm, P.tab, r, root_r);
+    else if (fm.prev_word == 1) lane_residue<W, MPC_FK_DIFF | LK_PW, NR>(c, fm, P.tab, r, root_r);
+    else lane_residue<W, MPC_FK_DIFF, NR>(c, fm, P.tab, r, root_r);
+    break;
+  case MPC_FK_WEIGHT:
+    if (fm.prev_word == 2) lane_residue<W, MPC_FK_WEIGHT | LK_PW2, NR>(c, fm, P.tab, r, root_r);
+    else if (fm.prev_word == 1) lane_residue<W, MPC_FK_WEIGHT | LK_PW, NR>(c, fm, P.tab, r, root_r);
+    else lane_residue<W, MPC_FK_WEIGHT, NR>(c, fm, P.tab, r, root_r);
+    break;
+  default:
+    if (fm.prev_word == 2) lane_residue<W, MPC_FK_WEIGHT2 | LK_PW2, NR>(c, fm, P.tab, r, root_r);
+    else if (fm.prev_word == 1) lane_residue<W, MPC_FK_WEIGHT2 | LK_PW, NR>(c, fm, P.tab, r, root_r);
+    else lane_residue<W, MPC_FK_WEIGHT2, NR>(c, fm, P.tab, r, root_r);
+    break;
+  }
+  if (fm.root != 0) {
+    // root to the front: residue[0] = natural[root] (the raw root byte), residue[j] = natural[j - 1] for 1 <= j <= root
+    const int rw = fm.root >> 2, rk = fm.root & 3;
+    const u32 rootraw = (lane_word_at<W>(c.x, rw) >> (8 * rk)) & 0xffu;
+    u32 prev = rootraw << 24;              // what enters byte 0 of word 0
+#pragma unroll
+    for (int e = 0; e < NR; e++) {
+      const u32 sh = alignbyte(r[e], prev, 3);                     // the natural bytes one position up
+      const int nb = fm.root + 1 - 4 * e;                          // bytes of this word at positions <= root
+      const u32 m = nb >= 4 ? ~0u : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+      prev = r[e];
+      r[e] = mask_sel(m, sh, r[e]);
+    }
+  }
+}
+
 template <int W>
 __device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcParams &P, LaneBest<W> &best,
-                                                 const u32 *__restrict__ scan_mask)
+                                                 const u32 *__restrict__ scan_mask, u64 need_mask)
 {
+  constexpr u32 NG = W / 4;
   best.z = 0;
   best.q = -1;
   best.root_r = 0;
@@ -338,60 +397,29 @@ __device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcP
   best.encb = 0;
 #pragma unroll
   for (int e = 0; e < W; e++) best.r[e] = 0;
-  for (int q = 0; q < P.n_pred; q++) {
+  for (int q = P.n_pred - 1; q >= 0; q--) {
     const MpcFastModule fm = P.fm[q];
+    const bool last = q == P.n_pred - 1;
     u32 r[W], root_r;
-    switch (fm.kind) {
-    case MPC_FK_ONEBASE:
-      if (fm.root == 0) {
-        lane_residue<W, MPC_FK_ONEBASE>(c, fm, P.tab, r, root_r);
-      } else {
-        const int rw = fm.root >> 2, rk = fm.root & 3;
-        const u32 xw = lane_word_at<W>(c.x, rw);
-        const u32 rb = ((xw >> (8 * rk)) & 0xffu) * 0x01010101u;     // line[root] in every byte
-        const u32 here = 0xffu << (8 * rk);
-#pragma unroll
-        for (int e = 0; e < W; e++) r[e] = bsub(c.x[e], e == rw ? (rb & ~here) : rb);   // predicted 0 at the root: raw root
-        root_r = 0;
-      }
-      break;
-    case MPC_FK_CONSEC: lane_residue<W, MPC_FK_CONSEC>(c, fm, P.tab, r, root_r); break;
-    case MPC_FK_DIFF:
-      if (fm.prev_word == 2) lane_residue<W, MPC_FK_DIFF | LK_PW2>(c, fm, P.tab, r, root_r);
-      else lane_residue<W, MPC_FK_DIFF>(c, fm, P.tab, r, root_r);
-      break;
-    case MPC_FK_WEIGHT:
-      if (fm.prev_word == 2) lane_residue<W, MPC_FK_WEIGHT | LK_PW2>(c, fm, P.tab, r, root_r);
-      else lane_residue<W, MPC_FK_WEIGHT>(c, fm, P.tab, r, root_r);
-      break;
-    default:
-      if (fm.prev_word == 2) lane_residue<W, MPC_FK_WEIGHT2 | LK_PW2>(c, fm, P.tab, r, root_r);
-      else lane_residue<W, MPC_FK_WEIGHT2>(c, fm, P.tab, r, root_r);
-      break;
+    if (!last) {
+      // upper bound of this module's leading zero rows from column group 0
+      lane_residue_rt<W, 4>(c, P, fm, r, root_r);
+      u32 g = scan_mask ? ((r[0] & scan_mask[0]) | (r[1] & scan_mask[1]) | (r[2] & scan_mask[2]) | (r[3] & scan_mask[3]))
+                        : (r[0] | r[1] | r[2] | r[3]);
+      const u32 p0 = (u32)__clz((int)fold8(g)) - 24u;                // first plane with a bit; 8 if none
+      const bool may_win = g == 0u || NG * p0 > best.z;
+      if ((__ballot(may_win) & need_mask) == 0) continue;            // wave-uniform
     }
-    if (fm.root != 0) {
-      // root to the front: residue[0] = natural[root], residue[j] = natural[j - 1] for 1 <= j <= root
-      const int rw = fm.root >> 2, rk = fm.root & 3;
-      const u32 rootraw = (lane_word_at<W>(r, rw) >> (8 * rk)) & 0xffu;
-      u32 prev = rootraw << 24;              // what enters byte 0 of word 0
-#pragma unroll
-      for (int e = 0; e < W; e++) {
-        const u32 sh = alignbyte(r[e], prev, 3);                     // the natural bytes one position up
-        const int nb = fm.root + 1 - 4 * e;                          // bytes of this word at positions <= root
-        const u32 m = nb >= 4 ? ~0u : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
-        prev = r[e];
-        r[e] = mask_sel(m, sh, r[e]);
-      }
-    }
+    lane_residue_rt<W, W>(c, P, fm, r, root_r);
     const u32 z = lane_leading_zero_rows<W>(r, scan_mask);
-    const bool take = best.z <= z;     // ties go to the later module (VPC.cpp:389)
-    best.z = take ? z : best.z;
-    best.q = take ? q : best.q;
-    best.root_r = take ? root_r : best.root_r;
-    best.cx = take ? (u32)fm.cx : best.cx;
-    best.encb = take ? (u32)P.enc_bits[P.start + q + 1] : best.encb;
+    const u32 m = (last || z > best.z) ? ~0u : 0u;
+    best.z = mask_sel(m, z, best.z);
+    best.q = (int)mask_sel(m, (u32)q, (u32)best.q);
+    best.root_r = mask_sel(m, root_r, best.root_r);
+    best.cx = mask_sel(m, (u32)fm.cx, best.cx);
+    best.encb = mask_sel(m, (u32)P.enc_bits[P.start + q + 1], best.encb);
 #pragma unroll
-    for (int e = 0; e < W; e++) best.r[e] = take ? r[e] : best.r[e];
+    for (int e = 0; e < W; e++) best.r[e] = mask_sel(m, r[e], best.r[e]);
   }
 }
 
@@ -659,7 +687,7 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
       if (keep_bits == 0) lane_last<W, NPT, 0, KINDS...>(c, P, best);
       else lane_seq<W, NPT, 0, KINDS...>(c, P, keep_bits, best, false);
     } else {
-      lane_seq_runtime<W>(c, P, best, scan_mask);
+      lane_seq_runtime<W>(c, P, best, scan_mask, need_mask);
     }
     // without any prediction module the empty scanned array encodes to 0 bits and the line is
     // reported uncompressed at that size (VPC.cpp:397-407 with an empty maxScanned)
@@ -761,8 +789,11 @@ __device__ __forceinline__ void lane_fetch(uint4 (&v)[NQ], const uint4 *__restri
 #ifndef MPC_LB_WAVES
 #define MPC_LB_WAVES 4
 #endif
+#ifndef MPC_LB_WAVES_RT
+#define MPC_LB_WAVES_RT 3   /* the run-time module loop: 3 waves per SIMD (168 VGPRs) measured best of 2 / 3 / 4 */
+#endif
 template <int W, bool OUT, int... KINDS>
-__global__ void __launch_bounds__(256, (W <= 16 ? MPC_LB_WAVES : 1))
+__global__ void __launch_bounds__(256, (W <= 16 ? (sizeof...(KINDS) > 0 ? MPC_LB_WAVES : MPC_LB_WAVES_RT) : 1))
 vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
                 uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats)
 {
@@ -795,6 +826,25 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
   // two line buffers: the next group of 64 lines is in flight while this one is evaluated
   uint4 va[NQ], vb[NQ];
   u32 qn = 0;          // deferred lines waiting in the wave's queue (wave-uniform)
+  if constexpr (sizeof...(KINDS) == 0) {
+    // run-time module loop: its body holds every predictor form, so the group code exists ONCE here (five
+    // copies of it, as below, do not fit the instruction cache); the next group's loads are still issued
+    // before the current group is evaluated
+    if (line0 < n_lines) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
+    while (line0 < n_lines) {
+      lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
+      lane_step<W, OUT, false, false>(va, line0, 0u, true, P, E, rs, qn);
+      line0 += stride;
+#pragma unroll
+      for (int i = 0; i < NQ; i++) va[i] = vb[i];
+      if ((++iter & 255u) == 0) {
+        lane_run_flush(rs, E.st, E.K, E.bins);
+        rs.cnt = 0;
+        rs.acc_r = 0;
+        rs.acc_r2 = 0;
+      }
+    }
+  } else
   for (;;) {
     // ---- streaming: until the trace ends or the queue is nearly full ----
     if (line0 < n_lines && qn <= kDeferHigh) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
