@@ -264,6 +264,7 @@ __device__ __forceinline__ u32 bdi_class_delta32(u32 base, u32 v)
 
 struct BdiScreen {
   u32 fails;      // bit c: the scan of combination c (B8D1, B8D2, B8D4, B4D1, B4D2, B2D1) certainly fails
+  u32 allimm;     // bit c: every value is an immediate of combination c (its cost is then a constant; exact counts: c >= 3)
   u32 floor[6];   // if it fails it costs at least this many bits
 };
 
@@ -273,6 +274,7 @@ __device__ __forceinline__ BdiScreen bdi_screen(const u32 *w)
   constexpr u32 L8 = 32u * NW;     // 8 * L
   BdiScreen sc;
   sc.fails = 0;
+  sc.allimm = 0;
   {   // 8-byte bases: a value can only be an immediate (any D) when its high word is 0 or -1
     constexpr int n = NW / 2;
     u32 cnt = 0;   // upper bound of the immediates of every D
@@ -315,6 +317,7 @@ __device__ __forceinline__ BdiScreen bdi_screen(const u32 *w)
     sc.fails |= (w[0] > 0xffffu && f2) ? 16u : 0u;
     sc.floor[3] = (u32)n + L8 - 8u * 3u * i1;
     sc.floor[4] = (u32)n + L8 - 8u * 2u * i2;
+    sc.allimm |= (i1 == (u32)n ? 8u : 0u) | (i2 == (u32)n ? 16u : 0u);
   }
   {   // 2-byte bases: immediates are the 16-bit values with a zero high byte
     constexpr int n = 2 * NW;
@@ -334,9 +337,74 @@ __device__ __forceinline__ BdiScreen bdi_screen(const u32 *w)
     }
     sc.fails |= (v0 > 0xffu && f) ? 32u : 0u;
     sc.floor[5] = (u32)n + L8 - 8u * ((u32)n - nz);
+    sc.allimm |= nz == 0u ? 32u : 0u;
   }
   return sc;
 }
+
+// One line (words w).  DEFER: exact scans that only a few lines of the wave's group need are not run for the
+// whole wave; those lines are flagged `deferred` instead (the caller queues them) and evaluated later, 64 at a
+// time, with DEFER = false.  Lanes that take no part pass active = false.
+#ifndef MPC_BDI_DEFER_MAX
+#define MPC_BDI_DEFER_MAX 12
+#endif
+template <int NW, bool DEFER>
+__device__ __forceinline__ void bdi_line(const u32 (&w)[NW], bool active, bool room, u32 &best, int &select, bool &deferred)
+{
+  constexpr u32 uncomp = 32u * NW;
+  u32 any = 0, rep = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    any |= w[i];
+    rep |= w[i] ^ w[i & 1];
+  }
+  best = uncomp;
+  select = 8;
+  deferred = false;
+  if (any == 0) {
+    best = 8;
+    select = 0;
+  } else if (rep == 0) {
+    best = 64;
+    select = 1;
+  } else if (active) {
+    // a combination whose scan certainly fails at a cost >= the lane's best so far cannot be
+    // selected; it is skipped when that holds on every active lane of the wave
+    const BdiScreen sc = bdi_screen<NW>(w);
+    u32 c;
+    // a scan that succeeds costs n + 8*(B + (n-1)*D) bits whatever the immediates are (imm*D +
+    // B + (n-imm-1)*D), and a failed one more: a combination whose success cost is not below
+    // the lane's best so far cannot be selected either
+#define MPC_BDI_TRY(IDX, B, D)                                                      \
+    {                                                                               \
+      constexpr u32 n_ = (NW * 4) / B, ok_cost_ = n_ + 8u * ((u32)B + (n_ - 1u) * (u32)D);   \
+      /* every value an immediate: n + 8 (n D + B + (n - n - 1) D) in 32-bit wrap (BDI.cpp:200), no scan needed */ \
+      constexpr u32 allimm_cost_ = n_ + 8u * (n_ * (u32)D + ((u32)B + (0u - 1u) * (u32)D));  \
+      const bool known_ = (sc.allimm >> IDX) & 1u;                                  \
+      if (known_ && best > allimm_cost_) { best = allimm_cost_; select = IDX + 2; } \
+      const bool want_ = !deferred && !known_ && ok_cost_ < best && (!((sc.fails >> IDX) & 1u) || sc.floor[IDX] < best);   \
+      const u64 wm_ = __ballot(want_);                                              \
+      if (wm_) {                                                                    \
+        if (DEFER && room && __popcll(wm_) <= MPC_BDI_DEFER_MAX) {                  \
+          deferred = deferred || want_;                                             \
+        } else {                                                                    \
+          c = bdi_check<B, D, NW>(w);                                               \
+          if (want_ && best > c) { best = c; select = IDX + 2; }                    \
+        }                                                                           \
+      }                                                                             \
+    }
+    MPC_BDI_TRY(0, 8, 1)
+    MPC_BDI_TRY(1, 8, 2)
+    MPC_BDI_TRY(2, 8, 4)
+    MPC_BDI_TRY(3, 4, 1)
+    MPC_BDI_TRY(4, 4, 2)
+    MPC_BDI_TRY(5, 2, 1)
+#undef MPC_BDI_TRY
+    if (best == uncomp) select = 8;
+  }
+}
+
+constexpr u32 kBdiQueue = 512;      // deferred lines per wave (LDS)
 
 template <int NW>   // words per line
 __global__ void __launch_bounds__(256)
@@ -344,58 +412,12 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
            int8_t *__restrict__ sel_out, u64 *gstats)
 {
   __shared__ u64 s_counts[MPC_BDI_RAW_LEN];
+  __shared__ u32 s_queue[4][kBdiQueue];
   if (threadIdx.x < MPC_BDI_RAW_LEN) s_counts[threadIdx.x] = 0;
   __syncthreads();
-  constexpr u32 uncomp = 32u * NW;
   // run-length accumulation per lane: (select, size) key, count
   u32 run_key = 0xffffffffu, run_cnt = 0;
-  for (u64 line = (u64)blockIdx.x * blockDim.x + threadIdx.x; line < n_lines; line += (u64)gridDim.x * blockDim.x) {
-    u32 w[NW];
-    const uint4 *src = lines + line * (NW / 4);
-#pragma unroll
-    for (int i = 0; i < NW / 4; i++) {
-      const uint4 q = src[i];
-      w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
-    }
-    u32 any = 0, rep = 0;
-#pragma unroll
-    for (int i = 0; i < NW; i++) {
-      any |= w[i];
-      rep |= w[i] ^ w[i & 1];
-    }
-    u32 best = uncomp;
-    int select = 8;
-    if (any == 0) {
-      best = 8;
-      select = 0;
-    } else if (rep == 0) {
-      best = 64;
-      select = 1;
-    } else {
-      // a combination whose scan certainly fails at a cost >= the lane's best so far cannot be
-      // selected; it is skipped when that holds on every active lane of the wave
-      const BdiScreen sc = bdi_screen<NW>(w);
-      u32 c;
-      // a scan that succeeds costs n + 8*(B + (n-1)*D) bits whatever the immediates are (imm*D +
-      // B + (n-imm-1)*D), and a failed one more: a combination whose success cost is not below
-      // the lane's best so far cannot be selected either
-#define MPC_BDI_TRY(IDX, B, D)                                                      \
-      {                                                                             \
-        constexpr u32 n_ = (NW * 4) / B, ok_cost_ = n_ + 8u * ((u32)B + (n_ - 1u) * (u32)D);   \
-        if (__ballot(ok_cost_ < best && (!((sc.fails >> IDX) & 1u) || sc.floor[IDX] < best))) {   \
-          c = bdi_check<B, D, NW>(w);                                               \
-          if (best > c) { best = c; select = IDX + 2; }                             \
-        }                                                                           \
-      }
-      MPC_BDI_TRY(0, 8, 1)
-      MPC_BDI_TRY(1, 8, 2)
-      MPC_BDI_TRY(2, 8, 4)
-      MPC_BDI_TRY(3, 4, 1)
-      MPC_BDI_TRY(4, 4, 2)
-      MPC_BDI_TRY(5, 2, 1)
-#undef MPC_BDI_TRY
-      if (best == uncomp) select = 8;
-    }
+  auto account = [&](u64 line, u32 best, int select) {
     const u32 size = best + 4u;
     if (sizes_out) sizes_out[line] = (uint16_t)size;
     if (sel_out) sel_out[line] = (int8_t)select;
@@ -409,7 +431,56 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
       run_cnt = 0;
     }
     run_cnt++;
+  };
+  auto fetch = [&](u32 (&w)[NW], u64 line) {
+    const uint4 *src = lines + line * (NW / 4);
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) {
+      const uint4 q = src[i];
+      w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+    }
+  };
+  const u32 lane = threadIdx.x & 63u;
+  u32 *queue = s_queue[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+  u32 qn = 0;                                   // queued lines of this wave (wave-uniform)
+  const bool can_defer = n_lines <= 0xffffffffull;      // queue entries are 32-bit line indices
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  // the queued lines, 64 at a time, every scan they need
+  auto drain = [&]() {
+    while (qn > 0u) {
+      const u32 take = qn < 64u ? qn : 64u;
+      qn -= take;
+      const bool active = lane < take;
+      const u64 line = active ? (u64)queue[qn + lane] : 0ull;
+      u32 w[NW];
+      fetch(w, line);
+      u32 best;
+      int select;
+      bool deferred;
+      bdi_line<NW, false>(w, active, false, best, select, deferred);
+      if (active) account(line, best, select);
+    }
+  };
+  // wave-uniform loop over groups of 64 lines (every lane stays in the loop: qn must stay uniform)
+  for (u64 line0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); line0 < n_lines; line0 += stride) {
+    const u64 line = line0 + lane;
+    const bool active = line < n_lines;
+    u32 w[NW];
+    fetch(w, active ? line : n_lines - 1);
+    u32 best;
+    int select;
+    bool deferred;
+    bdi_line<NW, (NW <= 16)>(w, active, can_defer, best, select, deferred);     // (128-byte lines: deferral measured slower)
+    const u64 dmask = __ballot(active && deferred);
+    if (dmask) {
+      const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)dmask, 0u));
+      if (active && deferred) queue[qn + rank] = (u32)line;
+      qn += (u32)__popcll(dmask);
+    }
+    if (active && !deferred) account(line, best, select);
+    if (qn + 64u > kBdiQueue) drain();        // wave-uniform: room for the next group's deferrals
   }
+  drain();
   if (run_cnt) {
     atomicAdd(&s_counts[run_key >> 16], (u64)run_cnt);
     atomicAdd(&s_counts[9], (u64)run_cnt * (u64)(run_key & 0xffffu));
