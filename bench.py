@@ -99,7 +99,7 @@ def make_evaluator(mpc, configs, algo: str, L: int, device: int):
     return {"BDI": mpc.BDI, "FPC": mpc.FPC, "BPC": mpc.BPC}[algo](L, device=device)
 
 
-def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, bytes_total, first_line=0, steps=5):
+def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, bytes_total, first_line=0, steps=8):
     """One sub-record: `workload` generated into (a prefix of) buf, `steps` launches timed with HIP events on
     the launch stream, the evaluator's own statistics checked for the line count."""
     kind, L = WORKLOADS[workload]
@@ -108,7 +108,8 @@ def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, byte
     torch.cuda.synchronize()
     ev = make_evaluator(mpc, configs, algo, L, device)
     sp = stream.cuda_stream
-    ev.compress_device(buf.data_ptr(), n, stream=sp)       # warm-up
+    for _ in range(2):                                     # warm-up
+        ev.compress_device(buf.data_ptr(), n, stream=sp)
     torch.cuda.synchronize()
     ev.reset()
     ms = []
