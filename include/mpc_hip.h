@@ -41,7 +41,7 @@ extern "C" {
 typedef struct mpc_handle mpc_handle;
 
 /* Which kernel a VPC configuration maps to (mpc_info.kernel_path). */
-#define MPC_PATH_VPC_FAST     1  /* plane-major scan, root 0, windowed tables: vpc_lane_kernel */
+#define MPC_PATH_VPC_FAST     1  /* (truncated) plane-major scan, windowed tables, any root for OneBase/Diff/Weight: vpc_lane_kernel */
 #define MPC_PATH_VPC_GENERIC  2  /* any table / root / scan order              */
 #define MPC_PATH_BDI          3
 #define MPC_PATH_FPC          4
@@ -65,8 +65,12 @@ typedef struct {
  * VPC::parseConfig reads (VPC.cpp:72-330).                                  */
 int mpc_create_vpc(const char *config_json_path, int device, mpc_handle **out);
 int mpc_create_vpc_from_string(const char *config_json_text, int device, mpc_handle **out);
-int mpc_create_bdi(unsigned line_size, int device, mpc_handle **out);
-/* `new comp::FPC(lineSize)` (FPC.h:91-97): frequent pattern compression of the line's 32-bit
+int mpc_create_bdi(unsigned line_size, int device, mpc_handle **out);   /* any multiple of 8 up to 256 (BDI.cpp:8) */
+/* Limits of mpc_create_vpc*: up to 32 modules (31 prediction modules), lineSize a multiple of 4 up to
+ * 256, clusters x histogram bins x 4 B <= 150 KiB (the per-workgroup histogram lives in LDS); MAE / MSE
+ * reproduce the reference's running doubles bit for bit when lineSize is a power of two and to 1e-12
+ * otherwise ("Deliberate deviations").
+ * `new comp::FPC(lineSize)` (FPC.h:91-97): frequent pattern compression of the line's 32-bit
  * words (FPC.cpp:7-88).  Per-line output: size in bits; `selected` is written as 0.
  * One definition where the reference has undefined behaviour: a zero run ends at the end of
  * the line (FPC.cpp:26 reads past it).  Parity is unpinned (no fixture).     */
@@ -89,7 +93,10 @@ const char *mpc_last_error(const mpc_handle *h);
  * the device.  size_bits_out (n x uint16: CompressLine's return value) and
  * selected_out (n x int8: VPC cluster -1..M-1, or BDIState 0..8) may each be
  * NULL.  Statistics accumulate in the handle exactly as m_Stat does.  The
- * call returns when the results are in the output buffers.                  */
+ * call returns when the results are in the output buffers.  Calls of up to
+ * 512 lines (the per-line CompressLine of an unchanged reference driver) are
+ * evaluated in place from a small pinned buffer: one launch, one stream
+ * synchronisation, no staging slots.                                        */
 int mpc_compress_batch(mpc_handle *h, const uint8_t *lines, uint64_t n_lines,
                        uint16_t *size_bits_out, int8_t *selected_out);
 
