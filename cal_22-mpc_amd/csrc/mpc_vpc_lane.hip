@@ -233,6 +233,24 @@ __host__ __device__ static inline size_t lane_stats_smem(int K, int bins)
   return 16 * (size_t)((2 * K * 8 + 15) / 16) + 16 * (size_t)(((K * bins + 1) * 4 + 15) / 16);
 }
 
+// First stage of pass 1 for all modules at once: the smallest of the modules' row-0 MSB words (residue words
+// 0..2) is non-zero exactly when every module shows an MSB; if that holds on every needed line, no module
+// but the last can win anywhere in the group -- one ballot instead of one per module (the common case on
+// incompressible data).
+template <int W, int NPT, int Q>
+__device__ __forceinline__ u32 lane_row0_min(const Lane<W> &, const MpcVpcParams &) { return ~0u; }
+
+template <int W, int NPT, int Q, int KIND, int... REST>
+__device__ __forceinline__ u32 lane_row0_min(const Lane<W> &c, const MpcVpcParams &P)
+{
+  if constexpr (Q + 1 == NPT) {
+    return ~0u;
+  } else {
+    const u32 m = lane_row0<W, KIND, 0, 3>(c, P.fm[Q], P.tab);
+    return min(m, lane_row0_min<W, NPT, Q + 1, REST...>(c, P));
+  }
+}
+
 template <int W, int NPT, int Q>
 __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &, const MpcVpcParams &, u64 &, u64 &, bool) { return 0; }
 
@@ -676,7 +694,9 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
     if constexpr (NPT > 0) {
       u64 defer_mask = 0;
       const bool allow_defer = !DRAIN && qn + (u32)((NPT - 1) * MPC_DEFER_MAX) <= kDeferCap;
-      const u32 keep_bits = lane_prefilters<W, NPT, 0, KINDS...>(c, P, need_mask, defer_mask, allow_defer);
+      u32 keep_bits = 0;
+      if ((__ballot(lane_row0_min<W, NPT, 0, KINDS...>(c, P) != 0u) & need_mask) != need_mask)
+        keep_bits = lane_prefilters<W, NPT, 0, KINDS...>(c, P, need_mask, defer_mask, allow_defer);
       if (!DRAIN && defer_mask) {          // wave-uniform and rare: some lines leave for the queue
         deferred = (defer_mask >> E.lane) & 1ull;
         const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(defer_mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)defer_mask, 0u));
@@ -720,6 +740,10 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
     // straight away (rs.enc_hot, wave-uniform).
     bool open = need;
     if (!rs.enc_hot) open = need && !lane_certified<W>(t);
+    if constexpr (MPC_ABLATE & 16) {                  // timing ablation: the certificate stays, the compressible path is cut off
+      if (__ballot(open)) E.st.hist[0] = 1u;          // (keeps the certificate alive; results are wrong)
+      open = false;
+    }
     u32 enc = uncomp;
     if (__ballot(open)) enc = lane_encode<W>(t);
     const bool keep = open && enc < uncomp && !no_pred;             // VPC.cpp:397-407
@@ -922,8 +946,10 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
                        first_line, *P, d_sizes, d_sel, d_stats);                                                   \
   }
   switch (P->L) {
-#ifndef MPC_DEV_ONLY64     // development builds (tools/ablate.sh): 64-byte lines only, seconds to compile
+#ifndef MPC_DEV_ONLY64     // development builds (tools/ab.py): 64-byte lines only (or 128 with MPC_DEV_ALSO128), seconds to compile
   case 32: MPC_LAUNCH(8); break;
+  case 128: MPC_LAUNCH(32); break;
+#elif defined(MPC_DEV_ALSO128)
   case 128: MPC_LAUNCH(32); break;
 #endif
   case 64: MPC_LAUNCH(16); break;
