@@ -269,7 +269,7 @@ __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcPar
         msb |= lane_row0<W, KIND, 3, 4>(c, P.fm[Q], P.tab);
         const u64 pass = ~__ballot(msb != 0) & need_mask;
         if (pass) {
-          if (MPC_DEFER_MAX > 0 && allow_defer && __popcll(pass) <= MPC_DEFER_MAX) {
+          if (MPC_DEFER_MAX > 0 && W <= 16 && allow_defer && __popcll(pass) <= MPC_DEFER_MAX) {   // (128-byte lines: measured slower)
             defer_mask |= pass;
             need_mask &= ~pass;
           } else {
