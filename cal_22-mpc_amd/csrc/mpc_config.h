@@ -205,6 +205,15 @@ inline bool is_plane_major_scan(const Module &m, int L)
   return true;
 }
 
+// byte-major scan table, possibly truncated: scanned bit i = plane i % 8 of byte i / 8
+inline bool is_byte_major_scan(const Module &m, int L)
+{
+  if (m.table_size > 8 * L) return false;
+  for (int i = 0; i < m.table_size; i++)
+    if (m.rows[(size_t)i] != i % 8 || m.cols[(size_t)i] != i / 8) return false;
+  return true;
+}
+
 inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
 {
   const int L = cfg.L, W = L / 4;
@@ -257,8 +266,17 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     const Module &m = cfg.modules[(size_t)(cfg.start + q)];
     MpcFastModule &f = P.fm[q];
     const std::string tag = "module " + std::to_string(cfg.start + q) + ": ";
-    if (!is_plane_major_scan(m, L)) { no(tag + "scan table is not a (truncated) plane-major identity"); break; }
-    if (m.table_size != cfg.modules[(size_t)cfg.start].table_size) { no(tag + "scan tables of different sizes"); break; }
+    // one scan order for the whole configuration: plane-major, or byte-major (a table of 8 entries or fewer is both:
+    // it is taken as whatever the first module is)
+    const Module &m0 = cfg.modules[(size_t)cfg.start];
+    const bool bm0 = !is_plane_major_scan(m0, L) && is_byte_major_scan(m0, L);
+    if (!(bm0 ? is_byte_major_scan(m, L) : is_plane_major_scan(m, L))) {
+      no(tag + "scan table is neither a (truncated) plane-major nor a (truncated) byte-major identity, or the modules differ");
+      break;
+    }
+    if (m.table_size != m0.table_size) { no(tag + "scan tables of different sizes"); break; }
+    P.byte_major = bm0 ? 1 : 0;
+    if (bm0) P.runtime_only = 1;
     // any root for OneBase / DiffBase / WeightBase: the residue array is the natural one with bytes 0..root
     // rotated by one position (ResidueModule.cpp:24-39); run-time module loop only
     f.root = m.root;
@@ -358,7 +376,7 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
         const int col = 4 * w + k;
         uint32_t bm = 0;
         for (int p = 0; p < 8; p++)
-          if (p * L + col < ts) bm |= 0x80u >> p;
+          if ((P.byte_major ? col * 8 + p : p * L + col) < ts) bm |= 0x80u >> p;
         word |= bm << (8 * k);
       }
       plan.tab.push_back(word);

@@ -57,7 +57,8 @@ struct MpcVpcParams {
   int32_t tab_words;    /* number of dwords in tab */
   int32_t trunc_off;    /* truncated plane-major scan table (TableSize < 8 L, the same for every module): dword offset in
                            tab of L/4 mask words (the bits of the XORed residue bytes that are scanned); -1: full table */
-  int32_t reserved1;
+  int32_t byte_major;   /* scan order of every module: 0 plane-major (scanned bit i = plane i / L of byte i % L), 1 byte-major
+                           (bit i = plane i % 8 of byte i / 8: row r of the scanned array = residue bytes 2r, 2r+1) */
   int32_t enc_bits[MPC_MAX_MODULES + 1];  /* index cluster+1 */
   struct MpcFastModule fm[MPC_MAX_PRED];
   struct MpcGenModule gm[MPC_MAX_PRED];

@@ -327,6 +327,55 @@ __device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &
   }
 }
 
+// ---- byte-major scan order (run-time module loop only) -----------------------------------------
+// scanned bit i = plane i % 8 of byte i / 8 (ScanModule.cpp:13-19 with Rows[i] = i % 8, Cols[i] = i / 8): row r
+// of the scanned array is the pair of XORed residue bytes (2r, 2r+1), most significant bit first.  A byte of
+// the XORed residue is zero exactly when the raw residue byte is (b ^ (b >> 1) and b ^ (msb ? 0x7f : 0) are
+// bijections that fix 0; the same holds for the leading bits kept by a truncated table), so the selector again
+// works on raw residues.
+
+// leading zero rows = (index of the first non-zero scanned byte) / 2; NR words looked at, none non-zero: `none`
+template <int W, int NR>
+__device__ __forceinline__ u32 lane_leading_zero_rows_bm(const u32 (&r)[W], const u32 *__restrict__ scan_mask, u32 none)
+{
+  u32 fe = NR, fw = 0;
+#pragma unroll
+  for (int e = NR - 1; e >= 0; e--) {
+    const u32 v = scan_mask ? (r[e] & scan_mask[e]) : r[e];
+    fe = v ? (u32)e : fe;
+    fw = v ? v : fw;
+  }
+  const u32 byte = 4u * fe + ((u32)__builtin_ctz(fw | 0x80000000u) >> 3);      // little-endian: the lowest set bit's byte
+  return fe == (u32)NR ? none : (byte >> 1);
+}
+
+// common encoder (FPCModule.cpp:19-85) over the 2 W rows of a byte-major scanned array
+template <int W>
+__device__ __forceinline__ u32 lane_encode_bm(const u32 (&t)[W])
+{
+  u32 bits = 0;
+  u64 Z = 0;                       // bit r: row r is zero
+#pragma unroll
+  for (int e = 0; e < W; e++) {
+    const u32 hw = perm(t[e], t[e], 0x02030001u);       // bytes swapped inside the halves: half = (first byte << 8) | second byte
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const u32 h = k ? (hw >> 16) : (hw & 0xffffu);    // the row, column 0 = bit 15
+      const u32 ones = (u32)__popc(h);
+      const bool adj = (h & (h >> 1)) != 0u;
+      const bool half_empty = (h & 0xff00u) == 0u || (h & 0x00ffu) == 0u;
+      const u32 cost = ones == 1u ? 7u : (ones == 2u && adj) ? 8u : half_empty ? 12u : 17u;
+      bits += h ? cost : 0u;
+      Z |= (u64)(h == 0u ? 1u : 0u) << (2 * e + k);
+    }
+  }
+  // zero rows are coded as runs in row order: 4 bits per run, 7 if longer than one row
+  const u64 all = W == 32 ? ~0ull : ((1ull << (2 * (W & 31))) - 1ull);
+  const u64 starts = Z & ~(Z << 1);
+  const u64 longer = starts & (Z >> 1) & all;
+  return bits + 4u * (u32)__popcll(starts) + 3u * (u32)__popcll(longer);
+}
+
 // word `idx` (wave-uniform) of the line
 template <int W>
 __device__ __forceinline__ u32 lane_word_at(const u32 (&x)[W], int idx)
@@ -422,14 +471,20 @@ __device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcP
     if (!last) {
       // upper bound of this module's leading zero rows from column group 0
       lane_residue_rt<W, 4>(c, P, fm, r, root_r);
-      u32 g = scan_mask ? ((r[0] & scan_mask[0]) | (r[1] & scan_mask[1]) | (r[2] & scan_mask[2]) | (r[3] & scan_mask[3]))
-                        : (r[0] | r[1] | r[2] | r[3]);
-      const u32 p0 = (u32)__clz((int)fold8(g)) - 24u;                // first plane with a bit; 8 if none
-      const bool may_win = g == 0u || NG * p0 > best.z;
+      bool may_win;
+      if (P.byte_major) {
+        // byte-major rows: a non-zero byte among the first 16 bounds the leading zero rows directly
+        may_win = lane_leading_zero_rows_bm<W, 4>(r, scan_mask, ~0u) > best.z;
+      } else {
+        u32 g = scan_mask ? ((r[0] & scan_mask[0]) | (r[1] & scan_mask[1]) | (r[2] & scan_mask[2]) | (r[3] & scan_mask[3]))
+                          : (r[0] | r[1] | r[2] | r[3]);
+        const u32 p0 = (u32)__clz((int)fold8(g)) - 24u;                // first plane with a bit; 8 if none
+        may_win = g == 0u || NG * p0 > best.z;
+      }
       if ((__ballot(may_win) & need_mask) == 0) continue;            // wave-uniform
     }
     lane_residue_rt<W, W>(c, P, fm, r, root_r);
-    const u32 z = lane_leading_zero_rows<W>(r, scan_mask);
+    const u32 z = P.byte_major ? lane_leading_zero_rows_bm<W, W>(r, scan_mask, 2u * W) : lane_leading_zero_rows<W>(r, scan_mask);
     const u32 m = (last || z > best.z) ? ~0u : 0u;
     best.z = mask_sel(m, z, best.z);
     best.q = (int)mask_sel(m, (u32)q, (u32)best.q);
@@ -739,13 +794,17 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
     // previous group of this wave still had compressible lines it is skipped and the encoder runs
     // straight away (rs.enc_hot, wave-uniform).
     bool open = need;
-    if (!rs.enc_hot) open = need && !lane_certified<W>(t);
+    const bool byte_major = NPT == 0 && P.byte_major;              // (no certificate for that order: the encoder always runs)
+    if (!rs.enc_hot && !byte_major) open = need && !lane_certified<W>(t);
     if constexpr (MPC_ABLATE & 16) {                  // timing ablation: the certificate stays, the compressible path is cut off
       if (__ballot(open)) E.st.hist[0] = 1u;          // (keeps the certificate alive; results are wrong)
       open = false;
     }
     u32 enc = uncomp;
-    if (__ballot(open)) enc = lane_encode<W>(t);
+    if (__ballot(open)) {
+      if (byte_major) enc = lane_encode_bm<W>(t);
+      else enc = lane_encode<W>(t);
+    }
     const bool keep = open && enc < uncomp && !no_pred;             // VPC.cpp:397-407
     const u64 keep_mask = __ballot(keep);
     rs.enc_hot = keep_mask != 0;

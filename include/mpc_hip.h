@@ -41,7 +41,7 @@ extern "C" {
 typedef struct mpc_handle mpc_handle;
 
 /* Which kernel a VPC configuration maps to (mpc_info.kernel_path). */
-#define MPC_PATH_VPC_FAST     1  /* (truncated) plane-major scan, windowed tables, any root for OneBase/Diff/Weight: vpc_lane_kernel */
+#define MPC_PATH_VPC_FAST     1  /* (truncated) plane- or byte-major scan, windowed tables, any root for OneBase/Diff/Weight: vpc_lane_kernel */
 #define MPC_PATH_VPC_GENERIC  2  /* any table / root / scan order              */
 #define MPC_PATH_BDI          3
 #define MPC_PATH_FPC          4

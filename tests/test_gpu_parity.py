@@ -241,6 +241,16 @@ def test_vpc_fast_path_nonzero_root_and_truncated_scan(mpc, oracle, configs, tra
         mods = [az, aws, configs.one_base(L, 0, True, trunc(ts)), configs.consecutive_base(L, 0, False, trunc(ts)),
                 configs.diff_base(L, prev4, diff, 0, True, trunc(ts)), configs.weight_base(L, prev4, w2, 0, True, trunc(ts))]
         _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:3000], expect_path=mpc.MPC_PATH_VPC_FAST)
+    # byte-major scan order (scanned bit i = plane i % 8 of byte i / 8: rows are byte pairs), full and truncated, any root
+    def bytemajor(ts=8 * L):
+        return {"TableSize": ts, "Rows": [i % 8 for i in range(ts)], "Cols": [i // 8 for i in range(ts)]}
+    for ts, root in ((8 * L, 0), (8 * L, 6), (8 * L - 20, 0), (5 * L + 3, 2), (24, 0)):
+        mods = [az, aws, configs.one_base(L, root, True, bytemajor(ts)), configs.consecutive_base(L, 0, False, bytemajor(ts)),
+                configs.diff_base(L, prev4, diff, root, True, bytemajor(ts)), configs.weight_base(L, prev4, w2, 0, False, bytemajor(ts))]
+        _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:3000], expect_path=mpc.MPC_PATH_VPC_FAST)
+    # mixing the two orders has no fast form
+    mods = [az, configs.one_base(L, 0, True, bytemajor()), configs.one_base(L, 0, False)]
+    _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:1500], expect_path=mpc.MPC_PATH_VPC_GENERIC)
     # both at once; and tables of different sizes have no fast form
     mods = [az, configs.diff_base(L, prev1, diff, 5, True, trunc(5 * L)), configs.weight_base(L, prev4, w2, 2, False, trunc(5 * L))]
     _check_vpc(mpc, oracle, configs.make_config(L, mods), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
