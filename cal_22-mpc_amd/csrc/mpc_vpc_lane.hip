@@ -1026,8 +1026,11 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
 #ifdef MPC_DEV_ONLY64
 #define MPC_LANE_SEQUENCES(X) X(OB, CS, DFP, WTP)
 #else
+// (the last row: the five data-type models of configs.mpc_config -- Bool/INT8, INT16, INT32/64, FP32, FP64 -- and the
+// 8-byte-element models alone)
 #define MPC_LANE_SEQUENCES(X) \
-  X(OB, CS, DFP, WTP) X(OB, CS, DFQ, WTQ) X(OB, CS, DF, WT) X(OB, CS) X(OB) X(CS) X(DF) X(WT) X(DFP) X(WTP)
+  X(OB, CS, DFP, WTP) X(OB, CS, DFQ, WTQ) X(OB, CS, DF, WT) X(OB, CS) X(OB) X(CS) X(DF) X(WT) X(DFP) X(WTP) \
+  X(DF, DF, DFP, CS, WTQ) X(DFQ) X(WTQ)
 #endif
 
 }  // namespace
