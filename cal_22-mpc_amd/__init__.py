@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
             "mpc_destroy": ([H], None),
             "mpc_get_info": ([H, C.POINTER(Info)], C.c_int),
             "mpc_last_error": ([H], C.c_char_p),
+            "mpc_path_reason": ([H], C.c_char_p),
             "mpc_compress_batch": ([H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p], C.c_int),
             "mpc_compress_batch_device": ([H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
             "mpc_sync": ([H], C.c_int),
@@ -108,7 +109,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "mpc_create_vpc", "mpc_create_vpc_from_string", "mpc_create_bdi", "mpc_create_fpc", "mpc_create_bpc", "mpc_destroy", "mpc_get_info",
-    "mpc_last_error", "mpc_compress_batch", "mpc_compress_batch_device", "mpc_sync", "mpc_stats_len",
+    "mpc_last_error", "mpc_path_reason", "mpc_compress_batch", "mpc_compress_batch_device", "mpc_sync", "mpc_stats_len",
     "mpc_stats_get", "mpc_stats_merge", "mpc_stats_set", "mpc_stats_reset", "mpc_stats_raw_len",
     "mpc_stats_copy_raw_device", "mpc_stats_from_raw", "mpc_config_describe",
     "mpc_compress_npy", "mpc_npy_shape", "mpc_compress_gpgpusim_log", "mpc_gpgpusim_log_line_size",
@@ -253,6 +254,7 @@ class VPC(_Evaluator):
         self.num_modules = self.info.num_modules
         self.hist_bins = self.info.hist_bins
         self.kernel_path = self.info.kernel_path
+        self.path_reason = (lib().mpc_path_reason(self._h) or b"").decode()   # why the generic kernel, if it is
 
     def result(self) -> Dict:
         """``VPCResult`` (reference ``VPC.h:36-76``) derived from the integer vector."""

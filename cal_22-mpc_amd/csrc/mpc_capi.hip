@@ -623,6 +623,11 @@ int mpc_get_info(const mpc_handle *h, mpc_info *info)
 
 const char *mpc_last_error(const mpc_handle *h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
+const char *mpc_path_reason(const mpc_handle *h)
+{
+  return (h && h->algorithm == 0 && !h->plan.fast) ? h->plan.why_generic.c_str() : "";
+}
+
 int mpc_compress_batch_device(mpc_handle *h, const void *d_lines, uint64_t n, uint16_t *d_sizes, int8_t *d_sel,
                               void *hip_stream)
 {

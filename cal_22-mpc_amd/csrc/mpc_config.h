@@ -253,8 +253,15 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     for (int j = 0; j < m.table_size; j++) plan.gtab.push_back((uint8_t)m.rows[(size_t)j]);
     g.off_cols = (int32_t)plan.gtab.size();
     for (int j = 0; j < m.table_size; j++) plan.gtab.push_back((uint8_t)m.cols[(size_t)j]);
+    while (plan.gtab.size() % 4) plan.gtab.push_back(0);
+    g.off_scan = (int32_t)plan.gtab.size();
+    for (int j = 0; j < m.table_size; j++) {
+      plan.gtab.push_back((uint8_t)m.cols[(size_t)j]);
+      plan.gtab.push_back((uint8_t)m.rows[(size_t)j]);
+    }
   }
   while (plan.gtab.size() % 16) plan.gtab.push_back(0);
+  P.gtab_bytes = (int32_t)plan.gtab.size();
 
   // ---- fast-path classification ----
   plan.fast = true;

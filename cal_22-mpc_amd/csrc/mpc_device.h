@@ -43,7 +43,8 @@ struct MpcGenModule {
   int32_t off_diff;   /* uint8 [L]  (uint8_t)DiffTable              */
   int32_t off_rows;   /* uint8 [table_size]                         */
   int32_t off_cols;   /* uint8 [table_size]                         */
-  int32_t pad[3];
+  int32_t off_scan;   /* uint16 [table_size]  Cols | Rows << 8 (4-byte aligned): one read per scanned bit */
+  int32_t pad[2];
 };
 
 struct MpcVpcParams {
@@ -64,6 +65,8 @@ struct MpcVpcParams {
   struct MpcGenModule gm[MPC_MAX_PRED];
   const uint32_t *tab;  /* fast path dword tables (device) */
   const uint8_t *gtab;  /* generic path byte tables (device) */
+  int32_t gtab_bytes;   /* size of gtab; the generic kernel keeps a copy in LDS when it fits */
+  int32_t reserved2;
 };
 
 /* Device-side raw statistics (uint64 each):

@@ -10,9 +10,21 @@
 
 // ---------------------------------------------------------------------------
 // generic VPC kernel: one lane per line, byte loops, any configuration.
-// Follows the reference stage by stage; the XOR stage is done on bytes.
+// Follows the reference stage by stage; the XOR stage is done on bytes.  The line and the transformed residue
+// of the module at hand live in LDS, one padded slice per lane (they are indexed by table entries; as private
+// arrays they would sit in scratch memory and every bit of the scan would be a memory access), and so do the
+// module tables when they fit (LDSTAB).  Per module the scanned rows are produced in order and fed straight to
+// the selector's leading-zero-row count and to the common encoder (FPCModule.cpp:19-85), so only (z, encoded
+// size) of the winner so far is kept -- the reference encodes the winner alone, with the same result.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(128)
+constexpr int kGenericThreads = 128;
+
+// threads per workgroup: fewer for long lines, whose slices are larger
+__host__ __device__ static inline int generic_threads(int L) { return L > 128 ? 64 : kGenericThreads; }
+__host__ __device__ static inline size_t generic_lane_smem(int L) { return (size_t)generic_threads(L) * 2u * (size_t)(L + 4); }
+
+template <bool LDSTAB>
+__global__ void __launch_bounds__(kGenericThreads)
 vpc_generic_kernel(const uint8_t *__restrict__ lines, u64 n_lines, MpcVpcParams P,
                    uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats)
 {
@@ -21,17 +33,25 @@ vpc_generic_kernel(const uint8_t *__restrict__ lines, u64 n_lines, MpcVpcParams 
   WgStats st;
   st.sums = reinterpret_cast<u64 *>(smem);
   st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * K * 8 + 15) / 16));
-  stats_init(st, K, bins);
+  const int slice = L + 4;
+  uint8_t *d = smem + vpc_stats_smem(K, bins) + (size_t)threadIdx.x * 2u * (size_t)slice;
+  uint8_t *t = d + slice;
   const uint8_t *gt = P.gtab;
+  if (LDSTAB) {
+    uint8_t *tabs = smem + vpc_stats_smem(K, bins) + generic_lane_smem(L);
+    for (int i = threadIdx.x; i < P.gtab_bytes / 4; i += blockDim.x)
+      reinterpret_cast<u32 *>(tabs)[i] = reinterpret_cast<const u32 *>(P.gtab)[i];
+    gt = tabs;
+  }
+  stats_init(st, K, bins);      // ends with __syncthreads()
 
   for (u64 line = (u64)blockIdx.x * blockDim.x + threadIdx.x; line < n_lines; line += (u64)gridDim.x * blockDim.x) {
-    uint8_t d[MPC_MAX_LINE], t[MPC_MAX_LINE];
-    uint16_t best[MPC_MAX_LINE / 2], cur[MPC_MAX_LINE / 2];
     const uint8_t *src = lines + line * (u64)L;
     bool zero = true, same = true;
-    for (int i = 0; i < L; i++) {
-      d[i] = src[i];
-      zero = zero && (d[i] == 0);
+    for (int i = 0; i < L; i += 4) {
+      const u32 w = *reinterpret_cast<const u32 *>(src + i);
+      *reinterpret_cast<u32 *>(d + i) = w;
+      zero = zero && w == 0u;
     }
     for (int i = 4; i < L; i++) same = same && (d[i] == d[i & 3]);
     int chosen;
@@ -46,6 +66,7 @@ vpc_generic_kernel(const uint8_t *__restrict__ lines, u64 n_lines, MpcVpcParams 
       size = 32u + (u32)P.enc_bits[2];
     } else {
       int best_q = -1, best_z = 0;
+      u32 best_enc = 0;
       for (int q = 0; q < P.n_pred; q++) {
         const MpcGenModule gm = P.gm[q];
         const uint8_t *base = gt + gm.off_base, *dif = gt + gm.off_diff;
@@ -72,30 +93,33 @@ vpc_generic_kernel(const uint8_t *__restrict__ lines, u64 n_lines, MpcVpcParams 
           t[j++] = gm.cx ? (uint8_t)(r ^ (r >> 1)) : (uint8_t)(r ^ ((r & 0x80) ? 0x7f : 0));
         }
         t[0] = d[gm.root];
-        const uint8_t *rows = gt + gm.off_rows, *cols = gt + gm.off_cols;
+        // scan (ScanModule.cpp:13-19) row by row; selector count and common encoder on the fly
+        const uint16_t *sc = reinterpret_cast<const uint16_t *>(gt + gm.off_scan);
         int z = 0;
         bool leading = true;
+        u32 enc = 0, run = 0;
         for (int r = 0; r < R; r++) {
           u32 v = 0;
-          for (int c = 0; c < 16; c++) {
-            const int i = 16 * r + c;
-            if (i < gm.table_size) v |= (u32)((t[cols[i]] >> (7 - rows[i])) & 1) << (15 - c);
+          const int i0 = 16 * r;
+          const int nb = gm.table_size - i0 < 16 ? gm.table_size - i0 : 16;      // entries of this row (rest of the array stays 0)
+          if (nb == 16) {
+            // a full row: the 16 table entries as 8 words, then 16 independent reads of t (the loads overlap)
+            const u32 *sw = reinterpret_cast<const u32 *>(sc + i0);
+            u32 ew[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) ew[k] = sw[k];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+              const u32 e = (ew[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+              v |= (u32)((t[e & 0xffu] >> (7u - (e >> 8))) & 1u) << (15 - c);
+            }
+          } else {
+            for (int c = 0; c < nb; c++) {
+              const u32 e = sc[i0 + c];
+              v |= (u32)((t[e & 0xffu] >> (7u - (e >> 8))) & 1u) << (15 - c);
+            }
           }
-          cur[r] = (uint16_t)v;
           if (leading && v == 0) z++; else leading = false;
-        }
-        if (best_z <= z) {
-          best_z = z;
-          best_q = q;
-          for (int r = 0; r < R; r++) best[r] = cur[r];
-        }
-      }
-      // common encoder
-      u32 enc = 0;
-      if (best_q >= 0) {
-        int run = 0;
-        for (int r = 0; r < R; r++) {
-          const u32 v = best[r];
           if (v == 0) { run++; continue; }
           if (run) enc += run > 1 ? 7u : 4u;
           run = 0;
@@ -106,7 +130,14 @@ vpc_generic_kernel(const uint8_t *__restrict__ lines, u64 n_lines, MpcVpcParams 
           else enc += 17u;
         }
         if (run) enc += run > 1 ? 7u : 4u;
+        if (best_z <= z) {     // ties go to the later module (VPC.cpp:389)
+          best_z = z;
+          best_q = q;
+          best_enc = enc;
+        }
       }
+      // with no prediction module the empty array encodes to 0 bits (VPC.cpp:397 with an empty maxScanned)
+      const u32 enc = best_q >= 0 ? best_enc : 0u;
       residue_stat = true;
       if (enc < 8u * (u32)L) {
         // note: with no prediction module the empty array encodes to 0 bits, cluster -1
@@ -868,17 +899,31 @@ __global__ void __launch_bounds__(256) read_probe_kernel(const uint4 *__restrict
 // ---------------------------------------------------------------------------
 // host-callable launchers (used by mpc_capi.hip)
 // ---------------------------------------------------------------------------
-extern "C" size_t mpc_vpc_generic_smem(const MpcVpcParams *P) { return vpc_stats_smem(P->M + 1, P->hist_bins); }
+// statistics + per lane (128 lanes) the line and one transformed residue, padded
+// statistics + per lane the line and one transformed residue (+ the module tables when all of it stays below 150 KiB)
+static inline bool generic_tabs_fit(const MpcVpcParams *P)
+{
+  return vpc_stats_smem(P->M + 1, P->hist_bins) + generic_lane_smem(P->L) + (size_t)P->gtab_bytes <= 150u * 1024u;
+}
+extern "C" size_t mpc_vpc_generic_smem(const MpcVpcParams *P)
+{
+  return vpc_stats_smem(P->M + 1, P->hist_bins) + generic_lane_smem(P->L) + (generic_tabs_fit(P) ? (size_t)P->gtab_bytes : 0u);
+}
 
 extern "C" hipError_t mpc_launch_vpc_generic(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
                                              int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
 {
-  const size_t smem = vpc_stats_smem(P->M + 1, P->hist_bins);
-  if (smem > (64u << 10))   // more than the default LDS allowance: many clusters x bins
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)smem);
-  hipLaunchKernelGGL(vpc_generic_kernel, dim3(grid), dim3(128), smem, stream, static_cast<const uint8_t *>(d_lines),
-                     n_lines, *P, d_sizes, d_sel, d_stats);
+  const size_t smem = mpc_vpc_generic_smem(P);
+  const bool tabs = generic_tabs_fit(P);
+  const void *fn = tabs ? reinterpret_cast<const void *>(&vpc_generic_kernel<true>) : reinterpret_cast<const void *>(&vpc_generic_kernel<false>);
+  if (smem > (64u << 10))   // more than the default LDS allowance
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (tabs)
+    hipLaunchKernelGGL(vpc_generic_kernel<true>, dim3(grid), dim3(generic_threads(P->L)), smem, stream, static_cast<const uint8_t *>(d_lines),
+                       n_lines, *P, d_sizes, d_sel, d_stats);
+  else
+    hipLaunchKernelGGL(vpc_generic_kernel<false>, dim3(grid), dim3(generic_threads(P->L)), smem, stream, static_cast<const uint8_t *>(d_lines),
+                       n_lines, *P, d_sizes, d_sel, d_stats);
   return hipGetLastError();
 }
 

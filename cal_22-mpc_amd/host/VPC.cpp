@@ -154,6 +154,8 @@ VPC::VPC(std::string configPath) : m_Handle(nullptr)
   m_HistBins = info.hist_bins;
   m_Stat = new VPCResult((unsigned)m_LineSize, m_NumModules);
   m_Stat->CompressorName = "Contrastive Clustering Compressor";
+  if (info.kernel_path == MPC_PATH_VPC_GENERIC)     // never silently: this path is some hundred times slower
+    fprintf(stderr, "note: this configuration runs on the generic (slow, exact) kernel: %s\n", mpc_path_reason(m_Handle));
 }
 
 VPC::~VPC() { mpc_destroy(m_Handle); }

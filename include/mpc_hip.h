@@ -84,6 +84,10 @@ int mpc_create_bpc(unsigned line_size, int device, mpc_handle **out);
 void mpc_destroy(mpc_handle *h);
 
 int mpc_get_info(const mpc_handle *h, mpc_info *info);
+/* Why a VPC configuration runs on the generic kernel (kernel_path == MPC_PATH_VPC_GENERIC, some hundred times slower
+ * than the fast kernel): one sentence naming the module and the property; "" for every other handle.  The
+ * `compressor` CLI prints it to stderr so that the slow path is never entered silently.                          */
+const char *mpc_path_reason(const mpc_handle *h);
 /* Last error text of this handle (or of the last failed create if h==NULL). */
 const char *mpc_last_error(const mpc_handle *h);
 

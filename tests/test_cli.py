@@ -261,6 +261,21 @@ def test_cli_bpc(cli, oracle, traces, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_generic_kernel_is_announced(cli, configs, traces, tmp_path):
+    """A configuration that only the generic (slow) kernel can run is never entered silently: stderr names the reason."""
+    d = tmp_path / "ds"
+    d.mkdir()
+    p = traces.save_npy(str(d / "t.npy"), traces.structured(300, 64))
+    perm = [int(x) for x in np.random.default_rng(1).permutation(512)]
+    cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, 0, True, {"TableSize": 512, "Rows": [q // 64 for q in perm],
+                                                                                    "Cols": [q % 64 for q in perm]})])
+    r = run([cli, "-a", "VPC", "-i", p, "-c", configs.write_config(cfg, str(tmp_path / "perm.json")), "-o", str(tmp_path)])
+    assert r.returncode == 0 and "generic (slow, exact) kernel" in r.stderr and "scan table" in r.stderr
+    r = run([cli, "-a", "VPC", "-i", p, "-c", configs.write_config(configs.probe_config(64), str(tmp_path / "probe.json")), "-o", str(tmp_path)])
+    assert r.returncode == 0 and "generic" not in r.stderr
+
+
+@pytest.mark.gpu
 def test_cli_line_size_mismatch_is_an_error(cli, configs, traces, tmp_path):
     d = tmp_path / "ds"
     d.mkdir()

@@ -378,7 +378,7 @@ def test_generic_and_fast_agree(mpc, configs, traces):
                                  configs.diff_base(L, [0] * L, [0] * L, 0, True),
                                  cfg["modules"]["3"], cfg["modules"]["4"], cfg["modules"]["5"]])
     gen = mpc.VPC(eq)
-    assert gen.kernel_path == mpc.MPC_PATH_VPC_GENERIC
+    assert gen.kernel_path == mpc.MPC_PATH_VPC_GENERIC and "windowed" in gen.path_reason and fast.path_reason == ""
     s2, c2 = gen.compress_lines(lines)
     assert (s1 == s2).all() and (c1 == c2).all()
     assert (fast.stats_vector() == gen.stats_vector()).all()
