@@ -875,8 +875,11 @@ __device__ __forceinline__ void lane_fetch(uint4 (&v)[NQ], const uint4 *__restri
 #ifndef MPC_LB_WAVES_RT
 #define MPC_LB_WAVES_RT 3   /* the run-time module loop: 3 waves per SIMD (168 VGPRs) measured best of 2 / 3 / 4 */
 #endif
+#ifndef MPC_LB_WAVES_128
+#define MPC_LB_WAVES_128 1
+#endif
 template <int W, bool OUT, int... KINDS>
-__global__ void __launch_bounds__(256, (W <= 16 ? (sizeof...(KINDS) > 0 ? MPC_LB_WAVES : MPC_LB_WAVES_RT) : 1))
+__global__ void __launch_bounds__(256, (W <= 16 ? (sizeof...(KINDS) > 0 ? MPC_LB_WAVES : MPC_LB_WAVES_RT) : MPC_LB_WAVES_128))
 vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
                 uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats)
 {
