@@ -244,6 +244,10 @@ int grid_for(const mpc_handle *h, u64 work_items, int block, int per_cu)
 {
   u64 need = (work_items + (u64)block - 1) / (u64)block;
   u64 cap = (u64)h->num_cus * (u64)per_cu;
+  // tests only: MPC_TEST_GRID caps the grid so that a wave walks many groups of lines (the kernels' deferred-line
+  // queues then fill and drain inside the loop even on small inputs)
+  static const long test_cap = []() { const char *e = getenv("MPC_TEST_GRID"); return e ? atol(e) : 0L; }();
+  if (test_cap > 0 && cap > (u64)test_cap) cap = (u64)test_cap;
   if (need < 1) need = 1;
   return (int)(need < cap ? need : cap);
 }

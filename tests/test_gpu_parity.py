@@ -764,3 +764,37 @@ def test_bench_two_rank_rehearsal_child_process():
     # random u32 blocks stay uncompressed at 515 bits, mixed blocks compress
     assert abs(d["config"]["compression_ratio"] - 512.0 / 515.0) < 1e-6
     assert c4["compression_ratio"] > 1.0
+
+
+def test_deferred_line_queues_fill_and_drain_inside_the_loop(oracle, configs, traces, tmp_path):
+    """The VPC and BDI kernels set lines aside into per-wave LDS queues (a few hundred entries) and drain them when
+    the queue is nearly full.  With the grid capped to two workgroups (MPC_TEST_GRID, tests only) every wave walks
+    hundreds of groups of lines, so the queues fill and drain many times inside the loop; results against the
+    oracle, in a fresh process (the cap is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import importlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+mpc = importlib.import_module("cal_22-mpc_amd"); C = importlib.import_module("cal_22-mpc_amd.configs"); T = importlib.import_module("cal_22-mpc_amd.traces")
+from oracle import oracle as O
+lines = np.concatenate([T.mixed(90000, 64), T.structured(60000, 64, seed=3), T.sine_f32(20000, 64), T.bdi_screen_stress(48000, 64),
+                        T.random_u32(30001, 64)])
+lines = lines[np.random.default_rng(7).permutation(len(lines))]
+for cfg in (C.probe_config(64), C.mpc_config(64)):
+    ev, o = mpc.VPC(cfg), O.VpcOracle(cfg)
+    s, k = ev.compress_lines(lines)
+    s_ref, k_ref = o.compress(lines)
+    assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all()
+ev, o = mpc.BDI(64), O.BdiOracle(64)
+s, k = ev.compress_lines(lines)
+s_ref, k_ref = o.compress(lines)
+assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all()
+print("queues ok", len(lines))
+""" % root
+    env = dict(os.environ, MPC_TEST_GRID="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0 and "queues ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
