@@ -11,7 +11,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for w in $WLS; do
   B="python3 $R/bench.py --workload $w --algo $ALGO --no-cpu-baseline --no-workloads --steps 10 --warmup 2"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${ALGO}_${w}_trace -o run -- $B > $OUT/${ALGO}_${w}_trace.log 2>&1
+  # the kernel-trace pass runs 40 timed steps so that the two warm-up launches weigh little in the summary's average
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${ALGO}_${w}_trace -o run -- python3 $R/bench.py --workload $w --algo $ALGO --no-cpu-baseline --no-workloads --steps 40 --warmup 2 > $OUT/${ALGO}_${w}_trace.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${ALGO}_${w}_fetch -o run -- $B > $OUT/${ALGO}_${w}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${ALGO}_${w}_write -o run -- $B > $OUT/${ALGO}_${w}_write.log 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d $OUT/${ALGO}_${w}_sq -o run -- $B > $OUT/${ALGO}_${w}_sq.log 2>&1
