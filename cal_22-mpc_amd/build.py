@@ -38,12 +38,26 @@ def _sources(d: str):
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
+    """libmpc_hip.so.  The translation units are compiled in parallel: the lane kernel file once per line size
+    (-DMPC_LANE_W=8/16/32) plus its dispatcher (-DMPC_LANE_W=0), the other kernels, the C ABI; then linked."""
     deps = _sources(CSRC) + [os.path.join(ROOT, "include", "mpc_hip.h")]
     if not force and _newer(LIB, deps):
         return LIB
-    cmd = [HIPCC, *FLAGS, "-shared", "-o", LIB,
-           os.path.join(CSRC, "mpc_vpc_lane.hip"), os.path.join(CSRC, "mpc_kernels.hip"),
-           os.path.join(CSRC, "mpc_capi.hip")]
+    objdir = os.path.join(HERE, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    lane = os.path.join(CSRC, "mpc_vpc_lane.hip")
+    units = [(lane, f"lane_w{w}.o", [f"-DMPC_LANE_W={w}"]) for w in (16, 32, 8, 0)]
+    units += [(os.path.join(CSRC, "mpc_kernels.hip"), "kernels.o", []), (os.path.join(CSRC, "mpc_capi.hip"), "capi.o", [])]
+    procs = []
+    for src, obj, extra in units:
+        cmd = [HIPCC, *FLAGS, *extra, "-c", src, "-o", os.path.join(objdir, obj)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + [os.path.join(objdir, obj) for _, obj, _ in units]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1008,6 +1008,9 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
                        first_line, *P, d_sizes, d_sel, d_stats);                                                   \
   }
   switch (P->L) {
+#if defined(MPC_LANE_W)    // one line size per translation unit (parallel build, see the end of this file)
+  case 4 * MPC_LANE_W: MPC_LAUNCH(MPC_LANE_W); break;
+#else
 #ifndef MPC_DEV_ONLY64     // development builds (tools/ab.py): 64-byte lines only (or 128 with MPC_DEV_ALSO128), seconds to compile
   case 32: MPC_LAUNCH(8); break;
   case 128: MPC_LAUNCH(32); break;
@@ -1015,6 +1018,7 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
   case 128: MPC_LAUNCH(32); break;
 #endif
   case 64: MPC_LAUNCH(16); break;
+#endif
   default: return hipErrorInvalidValue;
   }
 #undef MPC_LAUNCH
@@ -1038,6 +1042,13 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
 
 }  // namespace
 
+// Build layout.  Compiled as it is, this file holds every line size (development builds).  The product build
+// (cal_22-mpc_amd/build.py) compiles it four times in parallel: -DMPC_LANE_W=8 / 16 / 32 give the kernels of one
+// line size each and export mpc_launch_vpc_lane_w8 / _w16 / _w32; -DMPC_LANE_W=0 gives the dispatcher below.
+#define MPC_CAT2(a, b) a##b
+#define MPC_CAT(a, b) MPC_CAT2(a, b)
+
+#if !defined(MPC_LANE_W) || MPC_LANE_W == 0
 // 1 when the module sequence has an unrolled instantiation (else the run-time loop runs it)
 extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P)
 {
@@ -1049,11 +1060,33 @@ extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P)
 
 // statistics + the four waves' queues of deferred lines
 extern "C" size_t mpc_vpc_lane_smem(const MpcVpcParams *P) { return lane_stats_smem(P->M + 1, P->hist_bins) + 4u * kDeferCap * sizeof(u32); }
+#endif
+
+#if defined(MPC_LANE_W) && MPC_LANE_W == 0
+extern "C" hipError_t mpc_launch_vpc_lane_w8(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
+extern "C" hipError_t mpc_launch_vpc_lane_w16(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
+extern "C" hipError_t mpc_launch_vpc_lane_w32(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
 
 extern "C" hipError_t mpc_launch_vpc_lane(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
                                           int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
 {
-  const size_t smem = mpc_vpc_lane_smem(P);
+  switch (P->L) {
+  case 32: return mpc_launch_vpc_lane_w8(d_lines, n_lines, P, d_sizes, d_sel, d_stats, grid, stream);
+  case 64: return mpc_launch_vpc_lane_w16(d_lines, n_lines, P, d_sizes, d_sel, d_stats, grid, stream);
+  case 128: return mpc_launch_vpc_lane_w32(d_lines, n_lines, P, d_sizes, d_sel, d_stats, grid, stream);
+  default: return hipErrorInvalidValue;
+  }
+}
+#else
+#if defined(MPC_LANE_W)
+#define MPC_LAUNCH_NAME MPC_CAT(mpc_launch_vpc_lane_w, MPC_LANE_W)
+#else
+#define MPC_LAUNCH_NAME mpc_launch_vpc_lane
+#endif
+extern "C" hipError_t MPC_LAUNCH_NAME(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
+                                      int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
+{
+  const size_t smem = lane_stats_smem(P->M + 1, P->hist_bins) + 4u * kDeferCap * sizeof(u32);
   const u64 max_lines = 1ull << 30;     // 32-bit line indices inside the kernel
   for (u64 done = 0; done < n_lines; done += max_lines) {
     const u64 take = (n_lines - done) < max_lines ? (n_lines - done) : max_lines;
@@ -1072,3 +1105,4 @@ extern "C" hipError_t mpc_launch_vpc_lane(const void *d_lines, u64 n_lines, cons
   }
   return hipSuccess;
 }
+#endif
