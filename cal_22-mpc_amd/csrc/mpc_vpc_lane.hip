@@ -227,6 +227,21 @@ struct LaneBest {
 constexpr u32 kDeferCap = 512;      // queue entries per wave (2 KiB of LDS)
 constexpr u32 kDeferHigh = 384;     // the streaming loop hands over to a drain above this many entries
 
+// MPC_LANE_PAIR: a wave takes 128 consecutive lines at a time, as two groups of 64.  Normally the groups are the
+// first and the second 64 lines.  When the prefilters show that neighbouring lines alternate between two kinds
+// (arrays of 128-byte records; the interleaved integer / floating-point trace of BASELINE config 4) the wave
+// switches to PAIRED groups -- the even lines of the block, then the odd ones (lane i: lines 2i and 2i+1) -- so
+// that a group holds ONE kind of line and pays only for the modules that kind needs.  Paired groups cost memory
+// efficiency (every load instruction touches 64 cache lines instead of 32: +27 % measured on an HBM-bound trace
+// with paired groups throughout), so the wave probes with plain groups again every kPairProbe blocks and stays
+// with them unless the sign is back.  (Loading the lines as ever and exchanging them between neighbour lanes with
+// DPP moves was measured too: the second group's load is then not hidden behind the first group's evaluation,
+// and the interleaved trace ran 4 % slower than with the strided loads.)
+#ifndef MPC_LANE_PAIR
+#define MPC_LANE_PAIR 1
+#endif
+constexpr u32 kPairProbe = 64;
+
 // LDS bytes of the statistics: as vpc_stats_smem plus the spare histogram slot deferred lines are parked in
 __host__ __device__ static inline size_t lane_stats_smem(int K, int bins)
 {
@@ -252,11 +267,14 @@ __device__ __forceinline__ u32 lane_row0_min(const Lane<W> &c, const MpcVpcParam
 }
 
 template <int W, int NPT, int Q>
-__device__ __forceinline__ u32 lane_prefilters(const Lane<W> &, const MpcVpcParams &, u64 &, u64 &, bool) { return 0; }
+__device__ __forceinline__ u32 lane_prefilters(const Lane<W> &, const MpcVpcParams &, u64 &, u64 &, bool, bool &) { return 0; }
 
+// alt: set when a kept module is passed by lines of one parity only (at least 16 of them) while lines of the other
+// parity need the modules too -- the sign of a trace whose neighbouring lines alternate between two kinds (see
+// MPC_LANE_PAIR)
 template <int W, int NPT, int Q, int KIND, int... REST>
 __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcParams &P, u64 &need_mask, u64 &defer_mask,
-                                               bool allow_defer)
+                                               bool allow_defer, bool &alt)
 {
   if constexpr (Q + 1 == NPT) {
     return 0;
@@ -274,11 +292,15 @@ __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcPar
             need_mask &= ~pass;
           } else {
             bit = 1u << Q;
+            const u64 even = 0x5555555555555555ull;
+            if (MPC_LANE_PAIR && __popcll(pass) >= 16 && ((pass & even) == 0 || (pass & ~even) == 0) &&
+                __popcll(need_mask & ~pass) >= 16)
+              alt = true;
           }
         }
       }
     }
-    return bit | lane_prefilters<W, NPT, Q + 1, REST...>(c, P, need_mask, defer_mask, allow_defer);
+    return bit | lane_prefilters<W, NPT, Q + 1, REST...>(c, P, need_mask, defer_mask, allow_defer, alt);
   }
 }
 
@@ -706,17 +728,18 @@ __device__ __forceinline__ void lane_run_add(LaneRun &rs, u32 key, u32 sum_r, u3
 // untouched on the way; lines that only a rarely useful module could win with may be set aside into
 // the wave's queue (qn = entries waiting, wave-uniform).  Drain groups (DRAIN = true): this lane
 // evaluates queued line `dline` if `dvalid`, with every module it needs.
+// loff: this lane of a streaming group evaluates line line0 + loff; alt: see lane_prefilters.
 template <int W, bool OUT, bool FULL, bool DRAIN, int... KINDS>
-__device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u32 dline, bool dvalid, const MpcVpcParams &P,
-                                          const LaneEnv &E, LaneRun &rs, u32 &qn)
+__device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u32 loff, u32 dline, bool dvalid,
+                                          const MpcVpcParams &P, const LaneEnv &E, LaneRun &rs, u32 &qn, bool &alt)
 {
   constexpr int L = 4 * W;
   constexpr int NQ = W / 4;
   constexpr int NPT = sizeof...(KINDS);
   constexpr u32 uncomp = 8u * L;
-  const bool valid = DRAIN ? dvalid : (FULL ? true : (line0 + E.lane < E.n_lines));
+  const u32 line = DRAIN ? dline : line0 + loff;
+  const bool valid = DRAIN ? dvalid : (FULL ? true : (line < E.n_lines));
   const u64 valid_mask = (FULL && !DRAIN) ? ~0ull : __ballot(valid);
-  const u32 line = DRAIN ? dline : line0 + E.lane;
   bool deferred = false;
   Lane<W> c;
 #pragma unroll
@@ -751,7 +774,7 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
       const bool allow_defer = !DRAIN && qn + (u32)((NPT - 1) * MPC_DEFER_MAX) <= kDeferCap;
       u32 keep_bits = 0;
       if ((__ballot(lane_row0_min<W, NPT, 0, KINDS...>(c, P) != 0u) & need_mask) != need_mask)
-        keep_bits = lane_prefilters<W, NPT, 0, KINDS...>(c, P, need_mask, defer_mask, allow_defer);
+        keep_bits = lane_prefilters<W, NPT, 0, KINDS...>(c, P, need_mask, defer_mask, allow_defer, alt);
       if (!DRAIN && defer_mask) {          // wave-uniform and rare: some lines leave for the queue
         deferred = (defer_mask >> E.lane) & 1ull;
         const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(defer_mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)defer_mask, 0u));
@@ -906,8 +929,12 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
 
   // wave-uniform first line of the wave's group of 64: the address math stays on the scalar unit
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const u32 stride = gridDim.x * 256u;
-  u32 line0 = (blockIdx.x * 4u + wave) * 64u;
+  // (streaming groups of the unrolled sequences come in blocks of two, see MPC_LANE_PAIR)
+  constexpr u32 per_wave = 64u * (sizeof...(KINDS) > 0 ? MPC_LANE_PAIR + 1u : 1u);
+  const u32 stride = gridDim.x * 4u * per_wave;
+  u32 line0 = (blockIdx.x * 4u + wave) * per_wave;
+  bool paired = false, alt = false;    // wave-uniform
+  u32 pair_left = 0;
 
   // two line buffers: the next group of 64 lines is in flight while this one is evaluated
   uint4 va[NQ], vb[NQ];
@@ -919,7 +946,7 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
     if (line0 < n_lines) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
     while (line0 < n_lines) {
       lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
-      lane_step<W, OUT, false, false>(va, line0, 0u, true, P, E, rs, qn);
+      lane_step<W, OUT, false, false>(va, line0, E.lane, 0u, true, P, E, rs, qn, alt);
       line0 += stride;
 #pragma unroll
       for (int i = 0; i < NQ; i++) va[i] = vb[i];
@@ -933,16 +960,26 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
   } else
   for (;;) {
     // ---- streaming: until the trace ends or the queue is nearly full ----
-    if (line0 < n_lines && qn <= kDeferHigh) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
+#if MPC_LANE_PAIR
+    // blocks of 128 lines, as two groups: plain (lines 0..63, 64..127) or paired (even, odd), see MPC_LANE_PAIR
+    if (line0 < n_lines && qn <= kDeferHigh) lane_fetch<NQ>(va, lines, line0 + (paired ? 2u : 1u) * E.lane, n_lines);
     while (line0 < n_lines && qn <= kDeferHigh) {
-      lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
-      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(va, line0, 0u, true, P, E, rs, qn);
-      else lane_step<W, OUT, false, false, KINDS...>(va, line0, 0u, true, P, E, rs, qn);
-      line0 += stride;
-      if (line0 >= n_lines) break;
-      lane_fetch<NQ>(va, lines, line0 + stride + E.lane, n_lines);
-      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(vb, line0, 0u, true, P, E, rs, qn);
-      else lane_step<W, OUT, false, false, KINDS...>(vb, line0, 0u, true, P, E, rs, qn);
+      const u32 lstep = paired ? 2u : 1u, second = paired ? 1u : 64u;
+      lane_fetch<NQ>(vb, lines, line0 + second + lstep * E.lane, n_lines);
+      const bool full = line0 + 128u <= n_lines;
+      if (full) lane_step<W, OUT, true, false, KINDS...>(va, line0, lstep * E.lane, 0u, true, P, E, rs, qn, alt);
+      else lane_step<W, OUT, false, false, KINDS...>(va, line0, lstep * E.lane, 0u, true, P, E, rs, qn, alt);
+      // the mapping of the next block is fixed here, where its first group is requested
+      if (paired) {
+        if (--pair_left == 0u) paired = false;      // probe with plain groups
+      } else if (alt) {
+        paired = true;
+        pair_left = kPairProbe;
+      }
+      alt = false;
+      lane_fetch<NQ>(va, lines, line0 + stride + (paired ? 2u : 1u) * E.lane, n_lines);
+      if (full) lane_step<W, OUT, true, false, KINDS...>(vb, line0 + second, lstep * E.lane, 0u, true, P, E, rs, qn, alt);
+      else lane_step<W, OUT, false, false, KINDS...>(vb, line0 + second, lstep * E.lane, 0u, true, P, E, rs, qn, alt);
       line0 += stride;
       if ((++iter & 127u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
         lane_run_flush(rs, E.st, E.K, E.bins);
@@ -951,6 +988,26 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
         rs.acc_r2 = 0;
       }
     }
+#else
+    if (line0 < n_lines && qn <= kDeferHigh) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
+    while (line0 < n_lines && qn <= kDeferHigh) {
+      lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
+      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(va, line0, 1u, 0u, true, P, E, rs, qn, alt);
+      else lane_step<W, OUT, false, false, KINDS...>(va, line0, 1u, 0u, true, P, E, rs, qn, alt);
+      line0 += stride;
+      if (line0 >= n_lines) break;
+      lane_fetch<NQ>(va, lines, line0 + stride + E.lane, n_lines);
+      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(vb, line0, 1u, 0u, true, P, E, rs, qn, alt);
+      else lane_step<W, OUT, false, false, KINDS...>(vb, line0, 1u, 0u, true, P, E, rs, qn, alt);
+      line0 += stride;
+      if ((++iter & 127u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
+        lane_run_flush(rs, E.st, E.K, E.bins);
+        rs.cnt = 0;
+        rs.acc_r = 0;
+        rs.acc_r2 = 0;
+      }
+    }
+#endif
     // ---- drain: the queued lines, 64 at a time from the top of the queue ----
     while (qn > 0u) {
       const u32 take = qn < 64u ? qn : 64u;
@@ -958,7 +1015,7 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
       const bool dvalid = E.lane < take;
       const u32 dline = dvalid ? E.defer_q[qn + E.lane] : 0u;
       lane_fetch<NQ>(va, lines, dline, n_lines);
-      lane_step<W, OUT, false, true, KINDS...>(va, 0u, dline, dvalid, P, E, rs, qn);
+      lane_step<W, OUT, false, true, KINDS...>(va, 0u, 0u, dline, dvalid, P, E, rs, qn, alt);
     }
     if (line0 >= n_lines) break;
   }

@@ -798,3 +798,37 @@ print("queues ok", len(lines))
     env = dict(os.environ, MPC_TEST_GRID="2")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0 and "queues ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_paired_groups_on_alternating_lines(oracle, configs, traces, tmp_path):
+    """Where neighbouring lines alternate between two kinds the VPC lane kernel switches a wave to paired groups
+    (even lines of a 128-line block, then the odd ones) and probes with plain groups now and then.  With the grid
+    capped (MPC_TEST_GRID, tests only) every wave walks hundreds of blocks, so it switches back and forth; traces
+    that alternate throughout, that alternate in stretches between other data, and that end inside a block;
+    per-line results and statistics against the oracle, in a fresh process (the cap is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import importlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+mpc = importlib.import_module("cal_22-mpc_amd"); C = importlib.import_module("cal_22-mpc_amd.configs"); T = importlib.import_module("cal_22-mpc_amd.traces")
+from oracle import oracle as O
+for L, n in ((64, 150001), (32, 60037), (128, 50003)):
+    alt = T.mixed(n, L)
+    parts = [T.mixed(20000 + 77, L), T.random_u32(9000 + 5, L), T.mixed(30001, L, first_line=1), T.structured(12000, L, seed=3),
+             T.mixed(8192, L), T.zeros(300, L), T.mixed(4097, L)]
+    for lines in (alt, np.concatenate(parts)):
+        for cfg in (C.probe_config(L), C.mpc_config(L)):
+            ev, o = mpc.VPC(cfg), O.VpcOracle(cfg)
+            s, k = ev.compress_lines(lines)
+            s_ref, k_ref = o.compress(lines)
+            assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all(), (L, len(lines))
+            ev.close()
+print("paired ok")
+""" % root
+    env = dict(os.environ, MPC_TEST_GRID="3")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0 and "paired ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
