@@ -803,7 +803,7 @@ print("queues ok", len(lines))
 def test_paired_groups_on_alternating_lines(oracle, configs, traces, tmp_path):
     """Where neighbouring lines alternate between two kinds the VPC lane kernel switches a wave to paired groups
     (even lines of a 128-line block, then the odd ones) and probes with plain groups now and then.  With the grid
-    capped (MPC_TEST_GRID, tests only) every wave walks hundreds of blocks, so it switches back and forth; traces
+    capped to one workgroup (MPC_TEST_GRID, tests only) every wave walks hundreds of blocks, so it switches back and forth; traces
     that alternate throughout, that alternate in stretches between other data, and that end inside a block;
     per-line results and statistics against the oracle, in a fresh process (the cap is read once per process)."""
     import os
@@ -827,8 +827,23 @@ for L, n in ((64, 150001), (32, 60037), (128, 50003)):
             s_ref, k_ref = o.compress(lines)
             assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all(), (L, len(lines))
             ev.close()
+# the reference-derived whole-line vectors of the interleaved trace (tests/golden/ref_line_vectors.json: numbers of
+# the reference's compiled stage classes), now evaluated in paired groups
+sys.path.insert(0, %r)
+import ref_lines
+n_ref = 0
+for name, cfg, lines, c in ref_lines.load_cases():
+    if not name.startswith("mixed/"):
+        continue
+    size, sel = ref_lines.expected_sizes(O, cfg, lines, c)
+    ev = mpc.VPC(cfg)
+    s, k = ev.compress_lines(lines)
+    assert (s == size).all() and (k == sel).all(), name
+    ev.close()
+    n_ref += 1
+assert n_ref >= 2
 print("paired ok")
-""" % root
-    env = dict(os.environ, MPC_TEST_GRID="3")
+""" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, MPC_TEST_GRID="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0 and "paired ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
