@@ -266,7 +266,7 @@ __device__ __forceinline__ u32 bdi_check(const u32 *w)   // BDI.cpp:108-201
 // CompressLine keeps only strictly smaller sizes (BDI.cpp:40-66): when that cost is
 // not below the best size found so far the combination cannot be selected and need not
 // be evaluated.  bdi_screen() finds, per lane and cheaply, combinations whose scan
-// certainly fails (value 0 is the base, one of values 1..3 is a non-immediate witness
+// certainly fails (value 0 is the base, one of three later values is a non-immediate witness
 // whose delta does not fit) and a floor of the failed cost from an upper bound of the
 // immediates (exact for 4- and 2-byte bases); the kernel skips a combination when
 // "fails and floor >= best" holds on every active lane of the wave and runs the exact
@@ -293,6 +293,13 @@ __device__ __forceinline__ u32 bdi_class_delta32(u32 base, u32 v)
   return (sx && y == 0u) ? 64u : k;                       // base - v == -1 never fits
 }
 
+// the three witness values of a screen over n values: the second, the middle and the last one (on smooth data
+// -- samples of a waveform, counters -- the values far from the base show the misfitting delta first; values
+// 1..3 let such lines through to the exact scans)
+#ifndef MPC_BDI_WITNESS
+#define MPC_BDI_WITNESS(j, n) ((j) == 0 ? 1 : (j) == 1 ? (n) / 2 : (n) - 1)
+#endif
+
 struct BdiScreen {
   u32 fails;      // bit c: the scan of combination c (B8D1, B8D2, B8D4, B4D1, B4D2, B2D1) certainly fails
   u32 allimm;     // bit c: every value is an immediate of combination c (its cost is then a constant; exact counts: c >= 3)
@@ -311,12 +318,13 @@ __device__ __forceinline__ BdiScreen bdi_screen(const u32 *w)
     u32 cnt = 0;   // upper bound of the immediates of every D
 #pragma unroll
     for (int i = 0; i < n; i++) cnt += (w[2 * i + 1] + 1u <= 1u) ? 1u : 0u;
-    // value 0 is the base when it cannot be an immediate; witnesses: values 1..3 that cannot be
+    // value 0 is the base when it cannot be an immediate; witnesses: three later values that cannot be
     // immediates either and whose delta does not fit
     const bool base0 = w[1] + 1u > 1u;
     u32 kd = 0;
 #pragma unroll
-    for (int i = 1; i < (n < 4 ? n : 4); i++) {
+    for (int j = 0; j < (n < 4 ? n - 1 : 3); j++) {
+      const int i = MPC_BDI_WITNESS(j, n);
       const u32 dlo = w[0] - w[2 * i];
       const u32 dhi = w[1] - w[2 * i + 1] - (w[0] < w[2 * i] ? 1u : 0u);
       const u32 k = bdi_class64(dhi, dlo);
@@ -339,7 +347,8 @@ __device__ __forceinline__ BdiScreen bdi_screen(const u32 *w)
     }
     bool f1 = false, f2 = false;
 #pragma unroll
-    for (int i = 1; i < 4; i++) {
+    for (int j = 0; j < 3; j++) {
+      const int i = MPC_BDI_WITNESS(j, n);
       const u32 kd = bdi_class_delta32(w[0], w[i]);
       f1 = f1 || (w[i] > 0xffu && kd > 8u);
       f2 = f2 || (w[i] > 0xffffu && kd > 16u);
@@ -361,7 +370,8 @@ __device__ __forceinline__ BdiScreen bdi_screen(const u32 *w)
     const u32 v0 = w[0] & 0xffffu;
     bool f = false;
 #pragma unroll
-    for (int i = 1; i < 4; i++) {
+    for (int j = 0; j < 3; j++) {
+      const int i = MPC_BDI_WITNESS(j, n);
       const u32 v = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
       const u32 t = v0 - v + 128u;      // delta in [0,255] or [-128,-2]  <=>  t in [128,383] or [0,126]
       f = f || (v > 0xffu && !(t <= 383u && t != 127u));

@@ -98,10 +98,10 @@ def bdi_screen_stress(n_lines: int, line_size: int = 64, seed: int = 4242) -> np
     size B the line is random B-byte values (every scan fails) with 0 .. T+2
     immediates for each delta size (T = n / (8 (B - D)), the largest count for
     which a failed scan still costs >= 8 L bits), immediates placed at value 0, at
-    values 1..3 (the witness positions) or anywhere, negative / sign-extended
-    8-byte immediates, lines whose only misfitting delta lies beyond value 3, and
-    deltas of exactly -1.  Interleaved with plain random lines so that waves
-    hold both kinds."""
+    the screen's witness positions (values 1, n/2, n-1) or anywhere, negative /
+    sign-extended 8-byte immediates, lines whose only misfitting delta lies at a
+    value that is no witness, and deltas of exactly -1.  Interleaved with plain
+    random lines so that waves hold both kinds."""
     rng = np.random.default_rng(seed)
     L = line_size
     out = rng.integers(0, 256, (n_lines, L), dtype=np.uint8)
@@ -124,19 +124,20 @@ def bdi_screen_stress(n_lines: int, line_size: int = 64, seed: int = 4242) -> np
             if where == 0 and c:
                 pos[0] = 0
             elif where == 1 and c:
-                pos[0] = int(rng.integers(1, min(4, n)))
+                pos[0] = (1, n // 2, n - 1)[int(rng.integers(0, 3))]
             for p_ in pos:
                 v = int(rng.integers(0, 1 << (8 * d_sz)))
                 if B == 8 and k == 1:
                     v = (-int(rng.integers(2, 1 << (8 * d_sz - 1)))) % (1 << 64)   # negative immediate
                 vals[int(p_)] = v
         elif k == 2:
-            # all deltas fit except one beyond the witness positions
+            # all deltas fit except one at a value that is no witness
             base = vals[0]
             vals = [(base + int(x)) % (1 << bits) for x in rng.integers(0, 1 << (8 * d_sz - 1), n)]
             vals[0] = base
-            if n > 4:
-                vals[int(rng.integers(4, n))] = int(rng.integers(1 << (bits - 2), 1 << (bits - 1), dtype=np.uint64))
+            free = [j for j in range(2, n - 1) if j != n // 2]
+            if free:
+                vals[free[int(rng.integers(0, len(free)))]] = int(rng.integers(1 << (bits - 2), 1 << (bits - 1), dtype=np.uint64))
         elif k == 3:
             # everything fits (the combination is selected), with a -1 delta in every other such line
             base = vals[0]
