@@ -52,6 +52,10 @@ unsigned BDI::CompressLine(std::vector<uint8_t> &dataLine)
     printf("BDI: line of %zu bytes, expected %u.\n", dataLine.size(), m_LineSize);
     exit(1);
   }
+  if (LineBuffering()) {
+    BufferLine(dataLine);
+    return 0;
+  }
   uint16_t bits = 0;
   int rc = mpc_compress_batch(m_Handle, dataLine.data(), 1, &bits, nullptr);
   if (rc != MPC_OK) fail("BDI::CompressLine", rc, m_Handle);
@@ -60,12 +64,14 @@ unsigned BDI::CompressLine(std::vector<uint8_t> &dataLine)
 
 void BDI::CompressBatch(const uint8_t *lines, unsigned long long n)
 {
+  FlushLines();
   int rc = mpc_compress_batch(m_Handle, lines, n, nullptr, nullptr);
   if (rc != MPC_OK) fail("BDI::CompressBatch", rc, m_Handle);
 }
 
 unsigned long long BDI::CompressFile(const std::string &tracePath)
 {
+  FlushLines();
   uint64_t done = 0;
   const bool isLog = tracePath.size() > 4 && tracePath.compare(tracePath.size() - 4, 4, ".log") == 0;
   int rc = isLog ? mpc_compress_gpgpusim_log(m_Handle, tracePath.c_str(), nullptr, &done)
@@ -76,6 +82,7 @@ unsigned long long BDI::CompressFile(const std::string &tracePath)
 
 CompResult *BDI::GetResult()
 {
+  FlushLines();
   uint64_t v[12];
   int rc = mpc_stats_get(m_Handle, v, 12);
   if (rc != MPC_OK) fail("BDI::GetResult", rc, m_Handle);

@@ -55,6 +55,10 @@ unsigned BPC::CompressLine(std::vector<uint8_t> &dataLine)
     printf("BPC: line of %zu bytes, expected %u.\n", dataLine.size(), m_LineSize);
     exit(1);
   }
+  if (LineBuffering()) {
+    BufferLine(dataLine);
+    return 0;
+  }
   uint16_t bits = 0;
   int rc = mpc_compress_batch(m_Handle, dataLine.data(), 1, &bits, nullptr);
   if (rc != MPC_OK) fail("BPC::CompressLine", rc, m_Handle);
@@ -63,12 +67,14 @@ unsigned BPC::CompressLine(std::vector<uint8_t> &dataLine)
 
 void BPC::CompressBatch(const uint8_t *lines, unsigned long long n)
 {
+  FlushLines();
   int rc = mpc_compress_batch(m_Handle, lines, n, nullptr, nullptr);
   if (rc != MPC_OK) fail("BPC::CompressBatch", rc, m_Handle);
 }
 
 unsigned long long BPC::CompressFile(const std::string &tracePath)
 {
+  FlushLines();
   uint64_t done = 0;
   const bool isLog = tracePath.size() > 4 && tracePath.compare(tracePath.size() - 4, 4, ".log") == 0;
   int rc = isLog ? mpc_compress_gpgpusim_log(m_Handle, tracePath.c_str(), nullptr, &done)
@@ -79,6 +85,7 @@ unsigned long long BPC::CompressFile(const std::string &tracePath)
 
 CompResult *BPC::GetResult()
 {
+  FlushLines();
   uint64_t v[11];
   int rc = mpc_stats_get(m_Handle, v, 11);
   if (rc != MPC_OK) fail("BPC::GetResult", rc, m_Handle);

@@ -2,7 +2,8 @@
 // comp::Compressor (reference src/compressor/Compressor.h:18-33).  ADDITIVE:
 // CompressBatch()/CompressFile(), which the driver uses when the loader can hand
 // out many lines at once; the per-line CompressLine() keeps its signature and
-// meaning (it evaluates one line on the device and returns its size in bits).
+// meaning (it evaluates one line on the device and returns its size in bits), unless
+// the driver opts into SetLineBuffering().
 #ifndef MPC_HOST_COMPRESSOR_H
 #define MPC_HOST_COMPRESSOR_H
 
@@ -38,8 +39,42 @@ public:
   virtual unsigned long long CompressFile(const std::string &tracePath) = 0;
   virtual unsigned GetLineSize() = 0;
 
+  // ADDITIVE: buffered per-line mode, for drivers that keep the reference's loop (GetCacheline ->
+  // CompressLine per line, main.cpp:225-243 -- which never looks at CompressLine()'s return value).
+  // After SetLineBuffering(n), n > 0, CompressLine() copies the line into a host buffer of n lines and
+  // RETURNS 0; the buffer is evaluated as one batch when it is full, and by GetResult(), CompressBatch()
+  // and CompressFile().  The statistics are the same as without buffering.  Off (0) by default: every
+  // CompressLine() call then evaluates its line on the device and returns its size in bits.
+  void SetLineBuffering(unsigned long long lines)
+  {
+    FlushLines();
+    m_BufCap = lines;
+    m_LineBuf.clear();
+    m_LineBuf.shrink_to_fit();
+  }
+
 protected:
+  bool LineBuffering() const { return m_BufCap != 0; }
+  void BufferLine(const std::vector<uint8_t> &dataLine)
+  {
+    if (m_LineBuf.capacity() == 0) m_LineBuf.reserve((size_t)(m_BufCap * dataLine.size()));
+    m_LineBuf.insert(m_LineBuf.end(), dataLine.begin(), dataLine.end());
+    if (++m_BufLines == m_BufCap) FlushLines();
+  }
+  void FlushLines()
+  {
+    if (m_BufLines == 0) return;
+    const unsigned long long n = m_BufLines;
+    m_BufLines = 0;                 // (CompressBatch() flushes first: nothing left to flush then)
+    CompressBatch(m_LineBuf.data(), n);
+    m_LineBuf.clear();
+  }
+
   CompResult *m_Stat;
+
+private:
+  std::vector<uint8_t> m_LineBuf;
+  unsigned long long m_BufLines = 0, m_BufCap = 0;
 };
 
 }  // namespace comp

@@ -58,6 +58,10 @@ unsigned FPC::CompressLine(std::vector<uint8_t> &dataLine)
     printf("FPC: line of %zu bytes, expected %u.\n", dataLine.size(), m_LineSize);
     exit(1);
   }
+  if (LineBuffering()) {
+    BufferLine(dataLine);
+    return 0;
+  }
   uint16_t bits = 0;
   int rc = mpc_compress_batch(m_Handle, dataLine.data(), 1, &bits, nullptr);
   if (rc != MPC_OK) fail("FPC::CompressLine", rc, m_Handle);
@@ -66,12 +70,14 @@ unsigned FPC::CompressLine(std::vector<uint8_t> &dataLine)
 
 void FPC::CompressBatch(const uint8_t *lines, unsigned long long n)
 {
+  FlushLines();
   int rc = mpc_compress_batch(m_Handle, lines, n, nullptr, nullptr);
   if (rc != MPC_OK) fail("FPC::CompressBatch", rc, m_Handle);
 }
 
 unsigned long long FPC::CompressFile(const std::string &tracePath)
 {
+  FlushLines();
   uint64_t done = 0;
   const bool isLog = tracePath.size() > 4 && tracePath.compare(tracePath.size() - 4, 4, ".log") == 0;
   int rc = isLog ? mpc_compress_gpgpusim_log(m_Handle, tracePath.c_str(), nullptr, &done)
@@ -82,6 +88,7 @@ unsigned long long FPC::CompressFile(const std::string &tracePath)
 
 CompResult *FPC::GetResult()
 {
+  FlushLines();
   uint64_t v[11];
   int rc = mpc_stats_get(m_Handle, v, 11);
   if (rc != MPC_OK) fail("FPC::GetResult", rc, m_Handle);

@@ -166,6 +166,10 @@ unsigned VPC::CompressLine(std::vector<uint8_t> &dataLine)
     printf("VPC: line of %zu bytes, configuration lineSize is %d.\n", dataLine.size(), m_LineSize);
     exit(1);
   }
+  if (LineBuffering()) {
+    BufferLine(dataLine);
+    return 0;
+  }
   uint16_t bits = 0;
   int rc = mpc_compress_batch(m_Handle, dataLine.data(), 1, &bits, nullptr);
   if (rc != MPC_OK) fail("VPC::CompressLine", rc, m_Handle);
@@ -174,12 +178,14 @@ unsigned VPC::CompressLine(std::vector<uint8_t> &dataLine)
 
 void VPC::CompressBatch(const uint8_t *lines, unsigned long long n)
 {
+  FlushLines();
   int rc = mpc_compress_batch(m_Handle, lines, n, nullptr, nullptr);
   if (rc != MPC_OK) fail("VPC::CompressBatch", rc, m_Handle);
 }
 
 unsigned long long VPC::CompressFile(const std::string &tracePath)
 {
+  FlushLines();
   uint64_t done = 0;
   const bool isLog = tracePath.size() > 4 && tracePath.compare(tracePath.size() - 4, 4, ".log") == 0;
   int rc = isLog ? mpc_compress_gpgpusim_log(m_Handle, tracePath.c_str(), nullptr, &done)
@@ -190,6 +196,7 @@ unsigned long long VPC::CompressFile(const std::string &tracePath)
 
 CompResult *VPC::GetResult()
 {
+  FlushLines();
   uint64_t len = 0;
   mpc_stats_len(m_Handle, &len);
   std::vector<uint64_t> v(len);

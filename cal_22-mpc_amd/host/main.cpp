@@ -42,6 +42,7 @@ struct Args {
   std::string algorithm, input, config, output;
   bool has_algorithm = false, has_input = false, has_config = false, has_output = false, help = false;
   bool per_line = false;   // ADDITIVE --per-line: the reference's loop (GetCacheline -> CompressLine per line) instead of batches
+  unsigned long long line_buffer = 0;   // ADDITIVE --line-buffer N: that loop with Compressor::SetLineBuffering(N)
 };
 
 static bool take_value(int argc, char **argv, int &i, const std::string &arg, const char *shortf, const char *longf,
@@ -77,6 +78,7 @@ int main(int argc, char **argv)
     const std::string arg = argv[i];
     if (arg == "-h" || arg == "--help") { a.help = true; continue; }
     if (arg == "--per-line") { a.per_line = true; continue; }
+    if (arg == "--line-buffer" && i + 1 < argc) { a.per_line = true; a.line_buffer = strtoull(argv[++i], nullptr, 10); continue; }
     if (take_value(argc, argv, i, arg, "-a", "algorithm", a.algorithm, a.has_algorithm)) continue;
     if (take_value(argc, argv, i, arg, "-i", "input", a.input, a.has_input)) continue;
     if (take_value(argc, argv, i, arg, "-c", "config", a.config, a.has_config)) continue;
@@ -132,6 +134,7 @@ int main(int argc, char **argv)
   const std::string compOutputSavePath = outputDirPath + "/" + saveFileName + "_results.csv";
   const std::string compDetailedOutputSavePath = outputDirPath + "/" + saveFileName + "_results_detail.csv";
 
+  if (a.line_buffer) compressor->SetLineBuffering(a.line_buffer);
   comp::CompResult *compStat = compressLines(compressor, loader, a.per_line);
 
   // workload name = <parent directory>_<file stem> (reference main.cpp:141-157)

@@ -5,10 +5,12 @@
 // through the result object's own Print / PrintDetail, every returned size as uint16 to SIZES.bin, and
 // prints the line rate.  Test infrastructure (tests/test_cli.py), not product code.
 //
-//   perline_probe VPC cfg.json trace.npy out_results.csv out_detail.csv sizes.bin
-//   perline_probe BDI -        trace.npy out_results.csv out_detail.csv sizes.bin
+//   perline_probe VPC cfg.json trace.npy out_results.csv out_detail.csv sizes.bin [LINE_BUFFER]
+//   perline_probe BDI -        trace.npy out_results.csv out_detail.csv sizes.bin [LINE_BUFFER]
+// LINE_BUFFER > 0: the same loop after Compressor::SetLineBuffering(LINE_BUFFER) (CompressLine returns 0 then).
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,8 +21,8 @@
 
 int main(int argc, char **argv)
 {
-  if (argc != 7) {
-    std::fprintf(stderr, "usage: perline_probe VPC|BDI CONFIG|- TRACE.npy RESULTS.csv DETAIL.csv SIZES.bin\n");
+  if (argc != 7 && argc != 8) {
+    std::fprintf(stderr, "usage: perline_probe VPC|BDI CONFIG|- TRACE.npy RESULTS.csv DETAIL.csv SIZES.bin [LINE_BUFFER]\n");
     return 2;
   }
   const std::string algo = argv[1];
@@ -28,6 +30,8 @@ int main(int argc, char **argv)
   comp::Compressor *compressor = nullptr;
   if (algo == "VPC") compressor = new comp::VPC(std::string(argv[2]));
   else compressor = new comp::BDI(loader->GetCachelineSize());
+
+  if (argc == 8) compressor->SetLineBuffering(std::strtoull(argv[7], nullptr, 10));
 
   std::vector<uint16_t> sizes;
   trace::MemReq_t *memReq = new trace::MemReq_t;

@@ -290,7 +290,8 @@ def test_per_line_drop_in_matches_batch(cli, oracle, configs, traces, tmp_path):
     """The reference driver's own loop, unchanged (main.cpp:208-248): GetCacheline -> isEnd -> CompressLine per
     line -> GetResult -> Print / PrintDetail, driven (a) by tests/native/perline_probe.cpp through comp::VPC /
     comp::BDI and (b) by `compressor --per-line`.  Every returned size equals the oracle's and the CSV text
-    equals what the batch path writes for the same trace (.npy and GPGPU-Sim .log)."""
+    equals what the batch path writes for the same trace (.npy and GPGPU-Sim .log).  The same loop with the
+    additive Compressor::SetLineBuffering() (`--line-buffer N`) writes the same rows."""
     host = os.path.join(ROOT, "cal_22-mpc_amd", "host")
     probe = str(tmp_path / "perline_probe")
     srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp") and f != "main.cpp"]
@@ -318,6 +319,15 @@ def test_per_line_drop_in_matches_batch(cli, oracle, configs, traces, tmp_path):
         s_ref = o.compress(lines[:-1])[0]                      # LoaderNPY flags the last row as the end
         got = np.fromfile(out / "s.bin", dtype=np.uint16)
         assert len(got) == len(lines) - 1 and (got == s_ref).all()
+        # (a') the same loop with Compressor::SetLineBuffering(257): CompressLine returns 0, the rows are the same
+        outb = tmp_path / f"plb_{algo}"
+        outb.mkdir()
+        r = run([probe, algo, cfg_path if algo == "VPC" else "-", p, str(outb / "r.csv"), str(outb / "d.csv"), str(outb / "s.bin"), "257"])
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert not np.fromfile(outb / "s.bin", dtype=np.uint16).any()
+        assert (outb / "r.csv").read_text() == (out / "r.csv").read_text()
+        if algo == "VPC":            # (BDIResult has no detail rows)
+            assert (outb / "d.csv").read_text() == (out / "d.csv").read_text()
         # (b) the CLI with the per-line loop against the CLI's batch path: identical files
         ob, op = tmp_path / f"batch_{algo}", tmp_path / f"perline_{algo}"
         ob.mkdir()
@@ -327,8 +337,13 @@ def test_per_line_drop_in_matches_batch(cli, oracle, configs, traces, tmp_path):
         rp = run([cli, "-a", algo, "-i", p, "-o", str(op), "--per-line"] + extra)
         assert rb.returncode == 0 and rp.returncode == 0, rb.stdout + rp.stdout + rp.stderr
         assert rb.stdout == rp.stdout
+        opb = tmp_path / f"perline_buffered_{algo}"
+        opb.mkdir()
+        rpb = run([cli, "-a", algo, "-i", p, "-o", str(opb), "--line-buffer", "1000"] + extra)
+        assert rpb.returncode == 0 and rpb.stdout == rb.stdout, rpb.stdout + rpb.stderr
         stem = "probe64" if algo == "VPC" else "BDI"
         assert (ob / f"{stem}_results.csv").read_text() == (op / f"{stem}_results.csv").read_text()
+        assert (ob / f"{stem}_results.csv").read_text() == (opb / f"{stem}_results.csv").read_text()
         if algo == "VPC":
             assert (ob / f"{stem}_results_detail.csv").read_text() == (op / f"{stem}_results_detail.csv").read_text()
             # the probe's own rows (workload name "probe_trace") carry the same numbers
