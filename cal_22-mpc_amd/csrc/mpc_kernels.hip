@@ -186,6 +186,53 @@ vpc_generic_kernel(const uint8_t *__restrict__ lines, u64 n_lines, MpcVpcParams 
 }
 
 // ---------------------------------------------------------------------------
+// Staged loads (MPC_BPC_STAGE).  A lane that reads "its" line with NQ
+// 16-byte loads makes every load instruction touch 64 B-strided pieces of 32 cache lines; the same 64 lines read
+// as NQ fully coalesced, non-temporal loads (instruction k: units k*64 + lane of the group) stream 11 % faster
+// (tools/dev/membw.hip: 6.2 -> 6.9 TB/s with the transposition).  The group is brought into one-line-per-lane
+// form through 64 x 16 NQ bytes of LDS per wave: unit (line, piece) at line * NQ + (piece ^ f(line)),
+// f(line) = (line / (16 / NQ)) mod NQ -- no bank conflicts on either side.  Used by the BPC kernel (188 vector
+// instructions per 64 lines: 3.06 -> 2.78 ms per 16 GiB).  Where more arithmetic waits behind the line the LDS
+// round trip costs more than the loads gain: measured slower in the BDI (+3..5 %), FPC (+4 %) and VPC lane kernels
+// (+11 %, although their all-zero traces run 5 % faster).
+// ---------------------------------------------------------------------------
+#ifndef MPC_BPC_STAGE
+#define MPC_BPC_STAGE 1
+#endif
+template <int NQ>
+__device__ __forceinline__ u32 stage_unit(u32 line, u32 piece)
+{
+  return line * NQ + (piece ^ ((line / (16u / NQ)) & (NQ - 1u)));
+}
+
+template <int NQ>
+__device__ __forceinline__ void stage_fetch_rows(uint4 (&v)[NQ], const uint4 *__restrict__ lines, u64 line0, u32 lane, u64 n_lines)
+{
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  const u64 last = n_lines * NQ - 1u;      // clamped: units past the end re-read the last one (never evaluated)
+#pragma unroll
+  for (int k = 0; k < NQ; k++) {
+    const u64 u = min(line0 * NQ + (u32)(k * 64) + lane, last);
+    const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(lines + u));
+    v[k] = make_uint4(t.x, t.y, t.z, t.w);
+  }
+}
+
+template <int NQ>
+__device__ __forceinline__ void stage_rows_to_lines(uint4 (&v)[NQ], uint4 *stage, u32 lane)
+{
+#pragma unroll
+  for (int k = 0; k < NQ; k++) {
+    const u32 e = (u32)(k * 64) + lane;        // unit e of the group = piece e % NQ of line e / NQ
+    stage[stage_unit<NQ>(e / NQ, e % NQ)] = v[k];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < NQ; k++) v[k] = stage[stage_unit<NQ>(lane, (u32)k)];
+  __builtin_amdgcn_wave_barrier();             // the next group's writes stay behind these reads
+}
+
+// ---------------------------------------------------------------------------
 // BDI (reference BDI.cpp): one lane per line, line in registers.
 //
 // reduceSign (BDI.cpp:203-218) strips the leading ones of a negative 64-bit value down to
@@ -483,6 +530,7 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
   };
   const u32 lane = threadIdx.x & 63u;
   u32 *queue = s_queue[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+
   u32 qn = 0;                                   // queued lines of this wave (wave-uniform)
   const bool can_defer = n_lines <= 0xffffffffull;      // queue entries are 32-bit line indices
   const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -645,6 +693,22 @@ bpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
     if (bits_acc) atomicAdd(&s_counts[8], bits_acc);
     even = odd = words_acc = bits_acc = 0;
   };
+#if MPC_BPC_STAGE
+  __shared__ uint4 s_stage[4][64 * (NW / 4)];
+  const u32 lane = threadIdx.x & 63u;
+  uint4 *stage = s_stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+  for (u64 line0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); line0 < n_lines; line0 += (u64)gridDim.x * blockDim.x) {
+    const u64 line = line0 + lane;
+    u32 w[NW];
+    {
+      uint4 v[NW / 4];
+      stage_fetch_rows<NW / 4>(v, lines, line0, lane, n_lines);
+      stage_rows_to_lines<NW / 4>(v, stage, lane);
+#pragma unroll
+      for (int i = 0; i < NW / 4; i++) { w[4 * i] = v[i].x; w[4 * i + 1] = v[i].y; w[4 * i + 2] = v[i].z; w[4 * i + 3] = v[i].w; }
+    }
+    if (line >= n_lines) continue;
+#else
   for (u64 line = (u64)blockIdx.x * blockDim.x + threadIdx.x; line < n_lines; line += (u64)gridDim.x * blockDim.x) {
     u32 w[NW];
     const uint4 *src = lines + line * (NW / 4);
@@ -653,6 +717,7 @@ bpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
       const uint4 q = src[i];
       w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
     }
+#endif
     // deltas (low words d_r, sign s_r = 0 / ~0 = bits 32.. of the 33-bit delta) and X_r
     u32 X[ND];
     u32 orD = 0, andX = ~0u, top = 0, adj = 0;

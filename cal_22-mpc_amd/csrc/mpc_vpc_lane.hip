@@ -992,13 +992,13 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
     if (line0 < n_lines && qn <= kDeferHigh) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
     while (line0 < n_lines && qn <= kDeferHigh) {
       lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
-      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(va, line0, 1u, 0u, true, P, E, rs, qn, alt);
-      else lane_step<W, OUT, false, false, KINDS...>(va, line0, 1u, 0u, true, P, E, rs, qn, alt);
+      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(va, line0, E.lane, 0u, true, P, E, rs, qn, alt);
+      else lane_step<W, OUT, false, false, KINDS...>(va, line0, E.lane, 0u, true, P, E, rs, qn, alt);
       line0 += stride;
       if (line0 >= n_lines) break;
       lane_fetch<NQ>(va, lines, line0 + stride + E.lane, n_lines);
-      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(vb, line0, 1u, 0u, true, P, E, rs, qn, alt);
-      else lane_step<W, OUT, false, false, KINDS...>(vb, line0, 1u, 0u, true, P, E, rs, qn, alt);
+      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(vb, line0, E.lane, 0u, true, P, E, rs, qn, alt);
+      else lane_step<W, OUT, false, false, KINDS...>(vb, line0, E.lane, 0u, true, P, E, rs, qn, alt);
       line0 += stride;
       if ((++iter & 127u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
         lane_run_flush(rs, E.st, E.K, E.bins);
