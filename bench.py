@@ -134,7 +134,8 @@ def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, byte
 
 
 SUB_WORKLOADS = [("sine_f32", "VPC"), ("mixed", "VPC"), ("zeros", "VPC"), ("pointers_u64_128", "VPC"),
-                 ("random_u32", "BDI"), ("sine_f32", "BDI"), ("mixed", "BDI"), ("pointers_u64_128", "BDI")]
+                 ("random_u32", "BDI"), ("sine_f32", "BDI"), ("mixed", "BDI"), ("pointers_u64_128", "BDI"),
+                 ("random_u32", "FPC"), ("random_u32", "BPC")]
 
 
 def main():

@@ -199,6 +199,9 @@ vpc_generic_kernel(const uint8_t *__restrict__ lines, u64 n_lines, MpcVpcParams 
 #ifndef MPC_BPC_STAGE
 #define MPC_BPC_STAGE 1
 #endif
+#ifndef MPC_FPC_STAGE
+#define MPC_FPC_STAGE 1
+#endif
 template <int NQ>
 __device__ __forceinline__ u32 stage_unit(u32 line, u32 piece)
 {
@@ -584,9 +587,9 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
 // the reference are range tests: (v & 0xFFFFFFF8) in {0, 0xFFFFFFF8}  <=>  v + 8 < 16, etc.
 // A zero run costs 3 + 3 bits once, its further words nothing (FPC.cpp:20-32); a run ends
 // at the end of the line (the reference reads past it there: undefined behaviour, see
-// DESIGN.md "Deliberate deviations").  Per-lane counters are 16-bit fields of two 64-bit
-// registers, flushed to LDS every 1024 lines.
+// DESIGN.md "Deliberate deviations").
 // ---------------------------------------------------------------------------
+// prefix number of one word (the reference's tests in their order; used by the any-line-size kernel below)
 __device__ __forceinline__ u32 fpc_prefix(u32 v)
 {
   // width of v as a sign-extended number: nb significant bits below the sign
@@ -597,16 +600,46 @@ __device__ __forceinline__ u32 fpc_prefix(u32 v)
   return v == 0u ? 0u : nb <= 3u ? 1u : nb <= 7u ? 2u : nb <= 15u ? 3u : lo == 0u ? 4u : halves ? 5u : rep ? 6u : 7u;
 }
 
-__device__ __forceinline__ void fpc_flush(u64 &even, u64 &odd, u64 &bits, u64 *s_counts)
+// Classification without a prefix number (the unrolled kernels).  With y = v ^ (v << 1), bit i+1 of y says "bits i+1 and i of v differ", so
+// "v is a sign-extended k-bit number" (bits 31 .. k-1 all equal) is y < 2^k: prefixes 1, 2, 3 are y < 16, y < 256,
+// y < 65536 -- nested, and zero lies inside all of them -- and "both halfwords are sign-extended bytes" is
+// (y & 0xff00ff00) == 0.  Nested tests need no exclusivity: the kernel counts how many words pass each of them and
+// takes differences when it flushes.  The size of a line is linear in its counts:
+//   35 NW + 6 runs - 7 n(zero) - 4 n(y<16) - 8 n(y<256) - 16 (n(y<65536) + n4 + n5) - 24 n6
+// (n4, n5, n6: padded halfword / two sign-extended bytes / repeated bytes, each exclusive of the tests before it).
+struct FpcCounts { u32 z, c1, c2, c3, e4, e5, e6, runs; };
+
+__device__ __forceinline__ void fpc_word(u32 v, bool &prev_zero, FpcCounts &n)
 {
+  const u32 y = v ^ (v << 1);
+  const bool z = v == 0u;
+  const bool c1 = y < 16u, c2 = y < 256u, c3 = y < 65536u;
+  const bool c4 = (v << 16) == 0u;                                   // low halfword zero (FPC.cpp: padded halfword)
+  const bool c5 = (y & 0xff00ff00u) == 0u;
+  const bool c6 = v == __builtin_amdgcn_alignbit(v, v, 8);           // four equal bytes
+  const bool e4 = c4 && !c3, e5 = c5 && !c3 && !c4, e6 = c6 && !c3 && !c4 && !c5;
+  n.z += z ? 1u : 0u;
+  n.c1 += c1 ? 1u : 0u;
+  n.c2 += c2 ? 1u : 0u;
+  n.c3 += c3 ? 1u : 0u;
+  n.e4 += e4 ? 1u : 0u;
+  n.e5 += e5 ? 1u : 0u;
+  n.e6 += e6 ? 1u : 0u;
+  n.runs += (z && !prev_zero) ? 1u : 0u;
+  prev_zero = z;
+}
+
+// per-lane totals -> the workgroup's prefix counts (Prefix0..7) and bits
+__device__ __forceinline__ void fpc_flush(FpcCounts &t, u32 &words, u64 &bits, u64 *s_counts)
+{
+  const u32 c[8] = {t.z, t.c1 - t.z, t.c2 - t.c1, t.c3 - t.c2, t.e4, t.e5, t.e6, words - t.c3 - t.e4 - t.e5 - t.e6};
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const u64 e = (even >> (16 * k)) & 0xffffull, o = (odd >> (16 * k)) & 0xffffull;
-    if (e) atomicAdd(&s_counts[2 * k], e);
-    if (o) atomicAdd(&s_counts[2 * k + 1], o);
-  }
+  for (int k = 0; k < 8; k++)
+    if (c[k]) atomicAdd(&s_counts[k], (u64)c[k]);
   if (bits) atomicAdd(&s_counts[8], bits);
-  even = odd = bits = 0;
+  t = FpcCounts{0, 0, 0, 0, 0, 0, 0, 0};
+  words = 0;
+  bits = 0;
 }
 
 template <int NW>   // words per line
@@ -617,11 +650,25 @@ fpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
   __shared__ u64 s_counts[MPC_FPC_RAW_LEN];
   if (threadIdx.x < MPC_FPC_RAW_LEN) s_counts[threadIdx.x] = 0;
   __syncthreads();
-  // bits per prefix, 6 bits each: 6, 7, 11, 19, 19, 19, 11, 35 (PREFIX_SIZE + payload, FPC.h:8 + FPC.cpp)
-  constexpr u64 kBits = 6ull | (7ull << 6) | (11ull << 12) | (19ull << 18) | (19ull << 24) | (19ull << 30) |
-                        (11ull << 36) | (35ull << 42);
-  u64 even = 0, odd = 0, bits_acc = 0;   // counts of prefixes 0,2,4,6 / 1,3,5,7 in 16-bit fields; compressed bits
-  u32 since_flush = 0;
+  FpcCounts tot = {0, 0, 0, 0, 0, 0, 0, 0};
+  u32 words = 0;
+  u64 bits_acc = 0;
+#if MPC_FPC_STAGE
+  __shared__ uint4 s_stage[4][64 * (NW / 4)];
+  const u32 lane = threadIdx.x & 63u;
+  uint4 *stage = s_stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+  for (u64 line0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); line0 < n_lines; line0 += (u64)gridDim.x * blockDim.x) {
+    const u64 line = line0 + lane;
+    u32 w[NW];
+    {
+      uint4 v[NW / 4];
+      stage_fetch_rows<NW / 4>(v, lines, line0, lane, n_lines);
+      stage_rows_to_lines<NW / 4>(v, stage, lane);
+#pragma unroll
+      for (int i = 0; i < NW / 4; i++) { w[4 * i] = v[i].x; w[4 * i + 1] = v[i].y; w[4 * i + 2] = v[i].z; w[4 * i + 3] = v[i].w; }
+    }
+    if (line >= n_lines) continue;
+#else
   for (u64 line = (u64)blockIdx.x * blockDim.x + threadIdx.x; line < n_lines; line += (u64)gridDim.x * blockDim.x) {
     u32 w[NW];
     const uint4 *src = lines + line * (NW / 4);
@@ -630,28 +677,21 @@ fpc_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
       const uint4 q = src[i];
       w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
     }
-    u64 lc = 0;          // this line's counts, 8-bit field per prefix (at most NW <= 64 each)
-    u32 size = 0;
+#endif
+    FpcCounts n = {0, 0, 0, 0, 0, 0, 0, 0};      // this line's counts
     bool prev_zero = false;
 #pragma unroll
-    for (int i = 0; i < NW; i++) {
-      const u32 p = fpc_prefix(w[i]);
-      const u32 b = (u32)(kBits >> (6u * p)) & 63u;
-      size += (p == 0u && prev_zero) ? 0u : b;
-      prev_zero = p == 0u;
-      lc += 1ull << (8u * p);
-    }
-    even += lc & 0x00ff00ff00ff00ffull;
-    odd += (lc >> 8) & 0x00ff00ff00ff00ffull;
+    for (int i = 0; i < NW; i++) fpc_word(w[i], prev_zero, n);
+    // bits per prefix: 6, 7, 11, 19, 19, 19, 11, 35 (PREFIX_SIZE + payload, FPC.h:8 + FPC.cpp); a zero run pays once
+    const u32 size = 35u * NW + 6u * n.runs - 7u * n.z - 4u * n.c1 - 8u * n.c2 - 16u * (n.c3 + n.e4 + n.e5) - 24u * n.e6;
+    tot.z += n.z; tot.c1 += n.c1; tot.c2 += n.c2; tot.c3 += n.c3; tot.e4 += n.e4; tot.e5 += n.e5; tot.e6 += n.e6;
+    words += NW;
     bits_acc += size;
     if (sizes_out) sizes_out[line] = (uint16_t)size;
     if (sel_out) sel_out[line] = 0;
-    if (++since_flush == 1023u) {       // 1023 lines x 64 words < 2^16 per field
-      fpc_flush(even, odd, bits_acc, s_counts);
-      since_flush = 0;
-    }
+    if (words >= (1u << 30)) fpc_flush(tot, words, bits_acc, s_counts);      // far from overflow of the 32-bit totals
   }
-  fpc_flush(even, odd, bits_acc, s_counts);
+  fpc_flush(tot, words, bits_acc, s_counts);
   __syncthreads();
   if (threadIdx.x < MPC_FPC_RAW_LEN && s_counts[threadIdx.x]) atomicAdd(&gstats[threadIdx.x], s_counts[threadIdx.x]);
 }
