@@ -171,7 +171,7 @@ int create_vpc_from_text(const std::string &text, int device, mpc_handle **out)
     h->plan.params.gtab = h->d_gtab;
     // the statistics accumulators of a workgroup live in LDS
     const size_t smem = h->plan.fast ? mpc_vpc_lane_smem(&h->plan.params) : mpc_vpc_generic_smem(&h->plan.params);
-    if (smem > 150 * 1024) {
+    if (smem > 160 * 1024) {
       g_create_error = "histogram does not fit the 160 KiB LDS (too many clusters x bins)";
       rc = MPC_E_INVAL;
     }

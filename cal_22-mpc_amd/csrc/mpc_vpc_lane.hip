@@ -32,7 +32,6 @@
 #ifndef MPC_ABLATE
 #define MPC_ABLATE 0   // development-only timing ablations (tools/ablate.sh); results are WRONG when non-zero
 #endif
-
 namespace {
 
 // lane-kernel predictor kinds: MPC_FK_* plus LK_PW for periodic tables (MpcFastModule::prev_word):
@@ -42,6 +41,13 @@ constexpr int LK_PW = 8;
 constexpr int LK_PW2 = 16;    // the same two words back (prev_word == 2: BaseIndexTable[i] = i - 8)
 __device__ __host__ constexpr int lk_base(int kind) { return kind & 7; }
 __device__ __host__ constexpr int lk_dist(int kind) { return (kind & LK_PW2) ? 2 : ((kind & LK_PW) ? 1 : 0); }
+
+// The predictor tables are read through the CONSTANT address space: wave-uniform reads of it are scalar loads
+// (s_load into SGPRs) whatever else the kernel does.  Read as ordinary global memory they turn into vector loads as
+// soon as the compiler sees anything it must take for a store in front of them (the line ring's asm statements),
+// and a vector load's s_waitcnt vmcnt(0) also waits for every line request in flight.
+typedef const u32 __attribute__((address_space(4))) *ctab_t;
+__device__ __forceinline__ ctab_t lane_tab(const MpcVpcParams &P) { return (ctab_t)(u64)P.tab; }
 
 template <int W>
 struct Lane {
@@ -85,7 +91,7 @@ __device__ __forceinline__ u32 window_predict(u32 b, u32 c1, u32 c2, const MpcFa
 
 // base bytes of word e: own / previous word through v_perm_b32, or simply the previous word
 template <int W, int KIND>
-__device__ __forceinline__ u32 window_base(const Lane<W> &c, int e, const u32 *__restrict__ t)
+__device__ __forceinline__ u32 window_base(const Lane<W> &c, int e, ctab_t t)
 {
   constexpr int D = lk_dist(KIND);
   if (D && e >= D) return c.x[e - D];
@@ -95,7 +101,7 @@ __device__ __forceinline__ u32 window_base(const Lane<W> &c, int e, const u32 *_
 // residue word e of a DiffBase / WeightBase module.  full = false: only bit 7 of each
 // byte is meaningful (the MSBs the row-0 prefilter looks at)
 template <int W, int KIND, bool FULL = true>
-__device__ __forceinline__ u32 window_residue(const Lane<W> &c, int e, const u32 *__restrict__ t, const MpcFastModule &fm)
+__device__ __forceinline__ u32 window_residue(const Lane<W> &c, int e, ctab_t t, const MpcFastModule &fm)
 {
   const u32 b = window_base<W, KIND>(c, e, t);
   constexpr int D = lk_dist(KIND);
@@ -116,7 +122,7 @@ __device__ __forceinline__ u32 window_residue(const Lane<W> &c, int e, const u32
 // Residue bytes (root first == natural order for RootIndex 0) of one module;
 // root_r = the residue GetMAE / GetMSE see at the root position.  NR: only words 0..NR-1.
 template <int W, int KIND, int NR = W>
-__device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModule &fm, const u32 *__restrict__ tab,
+__device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModule &fm, ctab_t tab,
                                              u32 (&r)[W], u32 &root_r)
 {
   root_r = 0;
@@ -137,7 +143,7 @@ __device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModu
     root_r = (c.b0 - (c.x[0] >> 24)) & 0xffu;
   } else {
     // windowed tables; they force the predicted root byte to 0, so residue[0] = raw root
-    const u32 *t = tab + fm.tab_off;
+    ctab_t t = tab + fm.tab_off;
 #pragma unroll
     for (int e = 0; e < NR; e++) r[e] = window_residue<W, KIND>(c, e, t, fm);
   }
@@ -148,7 +154,7 @@ __device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModu
 // the MSBs of residue bytes 0..15 are all clear.  Returns the MSBs of residue words
 // E0..E1-1 ORed together (bit 7 of each byte).
 template <int W, int KIND, int E0, int E1>
-__device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &fm, const u32 *__restrict__ tab)
+__device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &fm, ctab_t tab)
 {
   u32 m = 0;
   if constexpr (lk_base(KIND) == MPC_FK_ONEBASE) {
@@ -161,7 +167,7 @@ __device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &
       m |= msb_of_bsub(c.x[e], e ? alignbyte(in_e, shuffled_word<W>(c.x, e - 1), 3) : (in_e << 8));
     }
   } else {
-    const u32 *t = tab + fm.tab_off;
+    ctab_t t = tab + fm.tab_off;
 #pragma unroll
     for (int e = E0; e < E1; e++) m |= window_residue<W, KIND, false>(c, e, t, fm);
   }
@@ -172,7 +178,7 @@ __device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &
 // non-zero row of the XORed planes equals that of the raw residue planes (DESIGN.md
 // "Selector on raw residues"), so the selector works on r directly.
 template <int W>
-__device__ __forceinline__ u32 lane_leading_zero_rows(const u32 (&r)[W], const u32 *__restrict__ scan_mask = nullptr)
+__device__ __forceinline__ u32 lane_leading_zero_rows(const u32 (&r)[W], ctab_t scan_mask = nullptr)
 {
   constexpr int NG = W / 4;
   u32 S[NG], G = 0;
@@ -224,28 +230,24 @@ struct LaneBest {
 #ifndef MPC_DEFER_MAX
 #define MPC_DEFER_MAX 8
 #endif
-constexpr u32 kDeferCap = 512;      // queue entries per wave (2 KiB of LDS)
-constexpr u32 kDeferHigh = 384;     // the streaming loop hands over to a drain above this many entries
+// (queue entries per wave: LaneEnv::defer_cap, chosen by the host with the LDS plan; the streaming loop hands over
+// to a drain above defer_cap - 64 entries)
 
-// MPC_LANE_PAIR: a wave takes 128 consecutive lines at a time, as two groups of 64.  Normally the groups are the
-// first and the second 64 lines.  When the prefilters show that neighbouring lines alternate between two kinds
-// (arrays of 128-byte records; the interleaved integer / floating-point trace of BASELINE config 4) the wave
-// switches to PAIRED groups -- the even lines of the block, then the odd ones (lane i: lines 2i and 2i+1) -- so
-// that a group holds ONE kind of line and pays only for the modules that kind needs.  Paired groups cost memory
-// efficiency (every load instruction touches 64 cache lines instead of 32: +27 % measured on an HBM-bound trace
-// with paired groups throughout), so the wave probes with plain groups again every kPairProbe blocks and stays
-// with them unless the sign is back.  (Loading the lines as ever and exchanging them between neighbour lanes with
-// DPP moves was measured too: the second group's load is then not hidden behind the first group's evaluation,
-// and the interleaved trace ran 4 % slower than with the strided loads.)
-#ifndef MPC_LANE_PAIR
-#define MPC_LANE_PAIR 1
-#endif
+// Paired groups.  A wave with a two-stage ring holds 128 consecutive lines (a block) and evaluates them as two groups
+// of 64.  Normally the groups are the first and the second 64 lines.  When the prefilters show that neighbouring
+// lines alternate between two kinds (arrays of 128-byte records; the interleaved integer / floating-point trace of
+// BASELINE config 4) the wave switches to PAIRED groups -- the even lines of the block, then the odd ones (lane i:
+// lines 2i and 2i+1) -- so that a group holds ONE kind of line and pays only for the modules that kind needs.  The
+// lines come out of LDS either way, so the choice costs no memory traffic (round 2 paid 16 % extra HBM traffic for
+// it with strided register loads); the wave still probes with plain groups every kPairProbe blocks and stays with
+// them unless the sign is back, because the read-out of a paired group has 2-way LDS bank conflicts and the next
+// block can only be requested after both groups have been read.
 constexpr u32 kPairProbe = 64;
 
 // LDS bytes of the statistics: as vpc_stats_smem plus the spare histogram slot deferred lines are parked in
 __host__ __device__ static inline size_t lane_stats_smem(int K, int bins)
 {
-  return 16 * (size_t)((2 * K * 8 + 15) / 16) + 16 * (size_t)(((K * bins + 1) * 4 + 15) / 16);
+  return 16 * (size_t)((2 * K * 8 + 15) / 16) + 16 * (size_t)(((K * bins + 2) * 4 + 15) / 16);    // (+ the workgroup's group counter)
 }
 
 // First stage of pass 1 for all modules at once: the smallest of the modules' row-0 MSB words (residue words
@@ -261,7 +263,7 @@ __device__ __forceinline__ u32 lane_row0_min(const Lane<W> &c, const MpcVpcParam
   if constexpr (Q + 1 == NPT) {
     return ~0u;
   } else {
-    const u32 m = lane_row0<W, KIND, 0, 3>(c, P.fm[Q], P.tab);
+    const u32 m = lane_row0<W, KIND, 0, 3>(c, P.fm[Q], lane_tab(P));
     return min(m, lane_row0_min<W, NPT, Q + 1, REST...>(c, P));
   }
 }
@@ -271,7 +273,7 @@ __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &, const MpcVpcPara
 
 // alt: set when a kept module is passed by lines of one parity only (at least 16 of them) while lines of the other
 // parity need the modules too -- the sign of a trace whose neighbouring lines alternate between two kinds (see
-// MPC_LANE_PAIR)
+// the paragraph on paired groups)
 template <int W, int NPT, int Q, int KIND, int... REST>
 __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcParams &P, u64 &need_mask, u64 &defer_mask,
                                                bool allow_defer, bool &alt)
@@ -282,9 +284,9 @@ __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcPar
     u32 bit = 0;
     if constexpr (!(MPC_ABLATE & 8)) {
       // words 0..2 first: on incompressible data 12 bytes almost always show an MSB
-      u32 msb = lane_row0<W, KIND, 0, 3>(c, P.fm[Q], P.tab);
+      u32 msb = lane_row0<W, KIND, 0, 3>(c, P.fm[Q], lane_tab(P));
       if ((__ballot(msb != 0) & need_mask) != need_mask) {
-        msb |= lane_row0<W, KIND, 3, 4>(c, P.fm[Q], P.tab);
+        msb |= lane_row0<W, KIND, 3, 4>(c, P.fm[Q], lane_tab(P));
         const u64 pass = ~__ballot(msb != 0) & need_mask;
         if (pass) {
           if (MPC_DEFER_MAX > 0 && W <= 16 && allow_defer && __popcll(pass) <= MPC_DEFER_MAX) {   // (128-byte lines: measured slower)
@@ -293,7 +295,7 @@ __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcPar
           } else {
             bit = 1u << Q;
             const u64 even = 0x5555555555555555ull;
-            if (MPC_LANE_PAIR && __popcll(pass) >= 16 && ((pass & even) == 0 || (pass & ~even) == 0) &&
+            if (__popcll(pass) >= 16 && ((pass & even) == 0 || (pass & ~even) == 0) &&
                 __popcll(need_mask & ~pass) >= 16)
               alt = true;
           }
@@ -316,7 +318,7 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
   constexpr bool last = Q + 1 == NPT;
   if (last || (keep_bits & (1u << Q))) {
     u32 r[W], root_r;
-    lane_residue<W, KIND>(c, P.fm[Q], P.tab, r, root_r);
+    lane_residue<W, KIND>(c, P.fm[Q], lane_tab(P), r, root_r);
     const u32 z = lane_leading_zero_rows<W>(r);
     // ties go to the later module (VPC.cpp:389)
     const u32 m = (!any_full || best.z <= z) ? ~0u : 0u;
@@ -340,7 +342,7 @@ template <int W, int NPT, int Q, int KIND, int... REST>
 __device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &P, LaneBest<W> &best)
 {
   if constexpr (Q + 1 == NPT) {
-    lane_residue<W, KIND>(c, P.fm[Q], P.tab, best.r, best.root_r);
+    lane_residue<W, KIND>(c, P.fm[Q], lane_tab(P), best.r, best.root_r);
     best.q = Q;
     best.cx = (u32)P.fm[Q].cx;
     best.encb = (u32)P.enc_bits[P.start + Q + 1];
@@ -358,7 +360,7 @@ __device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &
 
 // leading zero rows = (index of the first non-zero scanned byte) / 2; NR words looked at, none non-zero: `none`
 template <int W, int NR>
-__device__ __forceinline__ u32 lane_leading_zero_rows_bm(const u32 (&r)[W], const u32 *__restrict__ scan_mask, u32 none)
+__device__ __forceinline__ u32 lane_leading_zero_rows_bm(const u32 (&r)[W], ctab_t scan_mask, u32 none)
 {
   u32 fe = NR, fw = 0;
 #pragma unroll
@@ -430,7 +432,7 @@ __device__ __forceinline__ void lane_residue_rt(const Lane<W> &c, const MpcVpcPa
   switch (fm.kind) {
   case MPC_FK_ONEBASE:
     if (fm.root == 0) {
-      lane_residue<W, MPC_FK_ONEBASE, NR>(c, fm, P.tab, r, root_r);
+      lane_residue<W, MPC_FK_ONEBASE, NR>(c, fm, lane_tab(P), r, root_r);
     } else {
       const int rw = fm.root >> 2, rk = fm.root & 3;
       const u32 xw = lane_word_at<W>(c.x, rw);
@@ -441,21 +443,21 @@ __device__ __forceinline__ void lane_residue_rt(const Lane<W> &c, const MpcVpcPa
       root_r = 0;
     }
     break;
-  case MPC_FK_CONSEC: lane_residue<W, MPC_FK_CONSEC, NR>(c, fm, P.tab, r, root_r); break;
+  case MPC_FK_CONSEC: lane_residue<W, MPC_FK_CONSEC, NR>(c, fm, lane_tab(P), r, root_r); break;
   case MPC_FK_DIFF:
-    if (fm.prev_word == 2) lane_residue<W, MPC_FK_DIFF | LK_PW2, NR>(c, fm, P.tab, r, root_r);
-    else if (fm.prev_word == 1) lane_residue<W, MPC_FK_DIFF | LK_PW, NR>(c, fm, P.tab, r, root_r);
-    else lane_residue<W, MPC_FK_DIFF, NR>(c, fm, P.tab, r, root_r);
+    if (fm.prev_word == 2) lane_residue<W, MPC_FK_DIFF | LK_PW2, NR>(c, fm, lane_tab(P), r, root_r);
+    else if (fm.prev_word == 1) lane_residue<W, MPC_FK_DIFF | LK_PW, NR>(c, fm, lane_tab(P), r, root_r);
+    else lane_residue<W, MPC_FK_DIFF, NR>(c, fm, lane_tab(P), r, root_r);
     break;
   case MPC_FK_WEIGHT:
-    if (fm.prev_word == 2) lane_residue<W, MPC_FK_WEIGHT | LK_PW2, NR>(c, fm, P.tab, r, root_r);
-    else if (fm.prev_word == 1) lane_residue<W, MPC_FK_WEIGHT | LK_PW, NR>(c, fm, P.tab, r, root_r);
-    else lane_residue<W, MPC_FK_WEIGHT, NR>(c, fm, P.tab, r, root_r);
+    if (fm.prev_word == 2) lane_residue<W, MPC_FK_WEIGHT | LK_PW2, NR>(c, fm, lane_tab(P), r, root_r);
+    else if (fm.prev_word == 1) lane_residue<W, MPC_FK_WEIGHT | LK_PW, NR>(c, fm, lane_tab(P), r, root_r);
+    else lane_residue<W, MPC_FK_WEIGHT, NR>(c, fm, lane_tab(P), r, root_r);
     break;
   default:
-    if (fm.prev_word == 2) lane_residue<W, MPC_FK_WEIGHT2 | LK_PW2, NR>(c, fm, P.tab, r, root_r);
-    else if (fm.prev_word == 1) lane_residue<W, MPC_FK_WEIGHT2 | LK_PW, NR>(c, fm, P.tab, r, root_r);
-    else lane_residue<W, MPC_FK_WEIGHT2, NR>(c, fm, P.tab, r, root_r);
+    if (fm.prev_word == 2) lane_residue<W, MPC_FK_WEIGHT2 | LK_PW2, NR>(c, fm, lane_tab(P), r, root_r);
+    else if (fm.prev_word == 1) lane_residue<W, MPC_FK_WEIGHT2 | LK_PW, NR>(c, fm, lane_tab(P), r, root_r);
+    else lane_residue<W, MPC_FK_WEIGHT2, NR>(c, fm, lane_tab(P), r, root_r);
     break;
   }
   if (fm.root != 0) {
@@ -476,7 +478,7 @@ __device__ __forceinline__ void lane_residue_rt(const Lane<W> &c, const MpcVpcPa
 
 template <int W>
 __device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcParams &P, LaneBest<W> &best,
-                                                 const u32 *__restrict__ scan_mask, u64 need_mask)
+                                                 ctab_t scan_mask, u64 need_mask)
 {
   constexpr u32 NG = W / 4;
   best.z = 0;
@@ -689,7 +691,8 @@ struct LaneEnv {
   u64 first_line;
   uint16_t *sizes_out;
   int8_t *sel_out;
-  u32 *defer_q;      // this wave's queue of deferred lines (LDS, kDeferCap entries)
+  u32 *defer_q;      // this wave's queue of deferred lines (LDS, defer_cap entries)
+  u32 defer_cap;
 };
 
 // sum and sum of squares of the bytes of W words (two chains each: the reductions are
@@ -764,14 +767,14 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
   u32 sum_r = 0, sum_r2 = 0;        // residue statistics of this line (VPC.cpp:417-443)
 
   // truncated scan table (run-time loop only): per residue word the bits that are scanned
-  const u32 *scan_mask = (NPT == 0 && P.trunc_off >= 0) ? P.tab + P.trunc_off : nullptr;
+  ctab_t scan_mask = (NPT == 0 && P.trunc_off >= 0) ? lane_tab(P) + P.trunc_off : nullptr;
   if (need_mask) {     // wave-uniform: some line needs the prediction modules
     c.b0 = c.x[0] & 0xffu;
     c.rootb = perm(c.x[0], c.x[0], 0u);
     LaneBest<W> best;
     if constexpr (NPT > 0) {
       u64 defer_mask = 0;
-      const bool allow_defer = !DRAIN && qn + (u32)((NPT - 1) * MPC_DEFER_MAX) <= kDeferCap;
+      const bool allow_defer = !DRAIN && E.defer_cap != 0u && qn + (u32)((NPT - 1) * MPC_DEFER_MAX) <= E.defer_cap;
       u32 keep_bits = 0;
       if ((__ballot(lane_row0_min<W, NPT, 0, KINDS...>(c, P) != 0u) & need_mask) != need_mask)
         keep_bits = lane_prefilters<W, NPT, 0, KINDS...>(c, P, need_mask, defer_mask, allow_defer, alt);
@@ -890,8 +893,152 @@ __device__ __forceinline__ void lane_fetch(uint4 (&v)[NQ], const uint4 *__restri
   for (int i = 0; i < NQ; i++) v[i] = src[i];
 }
 
+// ---- line ring in LDS ---------------------------------------------------------------------------------------
+// The unrolled-sequence kernels do not load their lines into registers.  Every wave owns one or two STAGES of
+// 64 * L bytes in LDS; a group of 64 lines travels from global memory straight into a stage with
+// global_load_lds_dwordx4 (no destination registers, 1 KiB per instruction, fully coalesced, non-temporal) and is
+// read out transposed, one line per lane, right before it is evaluated; a stage is requested again as soon as it
+// has been read.  The LDS image of a stage is lane-linear per instruction (instruction j, lane l -> 16-byte unit
+// 64 j + l), so the bank swizzle sits on the SOURCE address: position (line, pos) holds piece pos ^ f(line) of the
+// line, f(line) = (line >> log2(16 / NQ)) & (NQ - 1), which makes the ds_read_b128 of a line-per-lane read-out
+// conflict-free (MI355X_MICROARCH.md, LDS: ds_read_b128 is served in groups of 16 lanes).
+//
+// Why a ring and not registers (round 3, tools/dev/ringbw.hip): the register double buffer cost 32
+// VGPRs and spilled at 4 waves per SIMD; its lane-per-line loads stream at 6.2 TB/s where these reach 7.0-7.15 TB/s
+// (all-zero trace 2.9 -> 2.4 ms per 16 GiB); and with two stages (128 consecutive lines resident) a wave can take
+// the even and the odd lines of the block as its two groups at no cost in memory traffic (paired groups, below).
+#ifndef MPC_RING_NT
+#define MPC_RING_NT 1   /* non-temporal DMA loads */
+#endif
+
+template <int NQ>
+__device__ __forceinline__ u32 ring_swz(u32 line) { return (line >> (NQ == 2 ? 3 : (NQ == 4 ? 2 : 1))) & (u32)(NQ - 1); }
+
+// byte offset (from the group's first byte) of the 16-byte unit that lane `lane` of DMA instruction j fetches,
+// less what the request's base and the instruction's offset field add (1 KiB per instruction)
+template <int NQ>
+__device__ __forceinline__ u32 ring_src_off(int j, u32 lane)
+{
+  const u32 q = 64u * (u32)j + lane, line = q / NQ, pos = q % NQ;
+  return 16u * (line * NQ + (pos ^ ring_swz<NQ>(line))) - 1024u * (u32)j;
+}
+
+// LDS byte offset (inside a stage) of piece k of line `ll` (0..63)
+template <int NQ>
+__device__ __forceinline__ u32 ring_rd_off(u32 ll, int k) { return 16u * (ll * NQ + ((u32)k ^ ring_swz<NQ>(ll))); }
+
+#if MPC_RING_NT
+#define MPC_GLDS_AUX " nt"
+#else
+#define MPC_GLDS_AUX ""
+#endif
+// up to 4 KiB (NP pieces of 1 KiB) from global memory into LDS at lds_dst; M0 carries the LDS base and is put back
+// (the compiler reserves it and does not see it change inside the statement).  No "memory" clobber: nothing the
+// compiler knows about is written (the stage is only ever read by ring_read's statement, and volatile statements
+// keep their order); with one, every table read behind it would stop being a scalar load.
+template <int NP>
+__device__ __forceinline__ void ring_glds(const u32 *lane_off, const void *gbase, u32 lds_dst)
+{
+  u32 keep;
+  if constexpr (NP == 4)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %5" MPC_GLDS_AUX "\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024" MPC_GLDS_AUX "\n\t"
+                 "global_load_lds_dwordx4 %3, %5 offset:2048" MPC_GLDS_AUX "\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072" MPC_GLDS_AUX "\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off[0]), "v"(lane_off[1]), "v"(lane_off[2]), "v"(lane_off[3]), "s"(gbase), "s"(lds_dst));
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3" MPC_GLDS_AUX "\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024" MPC_GLDS_AUX "\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off[0]), "v"(lane_off[1]), "s"(gbase), "s"(lds_dst));
+}
+
+// one group of 64 lines (NQ KiB) into the stage at lds_dst
+template <int NQ>
+__device__ __forceinline__ void ring_request(const u32 (&lane_off)[NQ], const uint4 *gbase_, u32 lds_dst_)
+{
+  // wave-uniform by construction; said so explicitly (the asm statements need scalar registers)
+  const u64 gb = reinterpret_cast<u64>(gbase_);
+  const u32 gb_hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(gb >> 32)), gb_lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)gb);
+  const uint4 *gbase = reinterpret_cast<const uint4 *>(((u64)gb_hi << 32) | (u64)gb_lo);      // (the builtin returns a signed int)
+  const u32 lds_dst = (u32)__builtin_amdgcn_readfirstlane((int)lds_dst_);
+  if constexpr (NQ == 8) {
+    ring_glds<4>(&lane_off[0], gbase, lds_dst);
+    ring_glds<4>(&lane_off[4], gbase + 256, lds_dst + 4096u);
+  } else {
+    ring_glds<NQ>(&lane_off[0], gbase, lds_dst);
+  }
+}
+
+// The streaming loop's state is wave-uniform by construction, but the compiler's divergence analysis gives up on values
+// that travel through the group code by reference (it then keeps them in vector registers and branches with EXEC masks:
+// +40 vector instructions per group, measured).  uni() says so explicitly: the value of the first active lane, in a scalar
+// register.
+__device__ __forceinline__ u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
+
+// wait until at most N of the wave's vector-memory operations (the DMA instructions, in issue order) are outstanding
+template <int N>
+__device__ __forceinline__ void ring_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N)); }
+
+// the line at LDS addresses a[0..NQ-1] (one 16-byte piece each) into v; the reads and their wait are one statement
+template <int NQ>
+__device__ __forceinline__ void ring_read(uint4 (&v)[NQ], const u32 (&a)[NQ])
+{
+  typedef u32 v4 __attribute__((ext_vector_type(4)));
+  v4 r[NQ];
+  if constexpr (NQ == 2)
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]) : "v"(a[0]), "v"(a[1]));
+  else if constexpr (NQ == 4)
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+  else
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+                 "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+#pragma unroll
+  for (int k = 0; k < NQ; k++) v[k] = make_uint4(r[k].x, r[k].y, r[k].z, r[k].w);
+}
+
+// ---- workgroup shape and LDS plan of the unrolled-sequence kernels ----------------------------------------------
+// One LARGE workgroup per CU: 16 waves (8 for 128-byte lines, whose group code needs two waves' registers per SIMD
+// lane) share ONE histogram, which leaves the LDS for the rings.  Four 256-thread workgroups per CU would hold four
+// histograms (58 KiB of the 160) and could not have two stages per wave.  A workgroup owns a contiguous range of
+// the trace and its waves draw blocks of it from a counter in LDS, so that they finish within one group of each
+// other (without it a large workgroup waits for its slowest wave: +7 % on random data, +12 % on the mixed trace).
+#ifndef MPC_LANE_WAVES
+#define MPC_LANE_WAVES 16
+#endif
+#ifndef MPC_LANE_WAVES_128
+#define MPC_LANE_WAVES_128 8
+#endif
+template <int W, int NPT>
+__host__ __device__ constexpr int lane_wpb() { return NPT == 0 ? 4 : (W <= 16 ? MPC_LANE_WAVES : MPC_LANE_WAVES_128); }
+
+// LDS layout: [sums][histogram + spare slot + block counter][queues: wpb x cap][pad to 1 KiB][rings: wpb x stages x 64 L]
+struct LaneLds {
+  u32 stages;      // ring stages per wave: 2 (0: the rings do not fit beside the histogram -- the run-time loop kernel takes the configuration)
+  u32 cap;         // queue entries per wave
+  size_t bytes;    // dynamic LDS of the launch
+};
+__host__ __device__ static inline size_t lane_ring_off(size_t stats_and_queues) { return (stats_and_queues + 1023u) & ~(size_t)1023u; }
+
+static LaneLds lane_lds_plan(const MpcVpcParams *P, int wpb, bool wants_queue)
+{
+  const size_t stats = lane_stats_smem(P->M + 1, P->hist_bins), SB = 64u * (size_t)P->L, lds = 160u << 10;
+  // queue entries per wave: what fits beside the histogram; 0 = no room, no line is ever set aside
+  const u32 caps[5] = {wants_queue ? 256u : 0u, wants_queue ? 192u : 0u, wants_queue ? 160u : 0u, wants_queue ? 96u : 0u, 0u};
+  for (u32 cap : caps) {
+    const size_t bytes = lane_ring_off(stats + (size_t)wpb * cap * sizeof(u32)) + (size_t)wpb * 2u * SB;
+    if (bytes <= lds) return LaneLds{2, cap, bytes};
+  }
+  return LaneLds{0, 0, 0};
+}
+
 // n_lines < 2^31 per launch (the host splits larger batches)
-// 64-byte lines and shorter: 4 workgroups (16 waves) per CU, i.e. at most 128 VGPRs
+// 64-byte lines and shorter: 16 waves per CU, i.e. at most 128 VGPRs
 #ifndef MPC_LB_WAVES
 #define MPC_LB_WAVES 4
 #endif
@@ -899,22 +1046,27 @@ __device__ __forceinline__ void lane_fetch(uint4 (&v)[NQ], const uint4 *__restri
 #define MPC_LB_WAVES_RT 3   /* the run-time module loop: 3 waves per SIMD (168 VGPRs) measured best of 2 / 3 / 4 */
 #endif
 #ifndef MPC_LB_WAVES_128
-#define MPC_LB_WAVES_128 1
+#define MPC_LB_WAVES_128 2
 #endif
+// ring_cfg: ring stages per wave (bits 0..7) | queue entries per wave << 8 (lane_lds_plan; the run-time loop ignores it)
 template <int W, bool OUT, int... KINDS>
-__global__ void __launch_bounds__(256, (W <= 16 ? (sizeof...(KINDS) > 0 ? MPC_LB_WAVES : MPC_LB_WAVES_RT) : MPC_LB_WAVES_128))
+__global__ void __launch_bounds__((64 * lane_wpb<W, sizeof...(KINDS)>()),
+                                  (W <= 16 ? (sizeof...(KINDS) > 0 ? MPC_LB_WAVES : MPC_LB_WAVES_RT) : MPC_LB_WAVES_128))
 vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
-                uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats)
+                uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats, u32 ring_cfg)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NQ = W / 4;             // 16-byte pieces per line
+  constexpr u32 WPB = lane_wpb<W, sizeof...(KINDS)>();       // waves per workgroup
   LaneEnv E;
   E.K = P.M + 1;
   E.bins = P.hist_bins;
   E.st.sums = reinterpret_cast<u64 *>(smem);
   E.st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * E.K * 8 + 15) / 16));
+  if (threadIdx.x == 0) E.st.hist[E.K * E.bins + 1] = 0;     // the workgroup's block counter
   stats_init(E.st, E.K, E.bins);   // ends with __syncthreads()
-  E.defer_q = reinterpret_cast<u32 *>(smem + lane_stats_smem(E.K, E.bins)) + (threadIdx.x >> 6) * kDeferCap;
+  E.defer_cap = ring_cfg >> 8;
+  E.defer_q = reinterpret_cast<u32 *>(smem + lane_stats_smem(E.K, E.bins)) + (threadIdx.x >> 6) * E.defer_cap;
   E.enc_zero = (u32)P.enc_bits[1];
   E.enc_same = 32u + (u32)P.enc_bits[2];
   E.enc_unc = (u32)P.enc_bits[0];
@@ -926,23 +1078,16 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
 
   LaneRun rs = {0xffffffffu, 0, 0, 0, false};
   u32 iter = 0;
-
-  // wave-uniform first line of the wave's group of 64: the address math stays on the scalar unit
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // (streaming groups of the unrolled sequences come in blocks of two, see MPC_LANE_PAIR)
-  constexpr u32 per_wave = 64u * (sizeof...(KINDS) > 0 ? MPC_LANE_PAIR + 1u : 1u);
-  const u32 stride = gridDim.x * 4u * per_wave;
-  u32 line0 = (blockIdx.x * 4u + wave) * per_wave;
-  bool paired = false, alt = false;    // wave-uniform
-  u32 pair_left = 0;
-
-  // two line buffers: the next group of 64 lines is in flight while this one is evaluated
-  uint4 va[NQ], vb[NQ];
+  bool alt = false;    // wave-uniform: the prefilters saw lines of two kinds alternate (paired groups)
+  uint4 va[NQ];
   u32 qn = 0;          // deferred lines waiting in the wave's queue (wave-uniform)
   if constexpr (sizeof...(KINDS) == 0) {
-    // run-time module loop: its body holds every predictor form, so the group code exists ONCE here (five
-    // copies of it, as below, do not fit the instruction cache); the next group's loads are still issued
-    // before the current group is evaluated
+    // run-time module loop: its body holds every predictor form, so the group code exists ONCE here; lines are
+    // loaded into registers, the next group's loads are issued before the current group is evaluated
+    uint4 vb[NQ];
+    const u32 stride = gridDim.x * WPB * 64u;
+    u32 line0 = (blockIdx.x * WPB + wave) * 64u;
     if (line0 < n_lines) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
     while (line0 < n_lines) {
       lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
@@ -957,67 +1102,121 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
         rs.acc_r2 = 0;
       }
     }
-  } else
-  for (;;) {
-    // ---- streaming: until the trace ends or the queue is nearly full ----
-#if MPC_LANE_PAIR
-    // blocks of 128 lines, as two groups: plain (lines 0..63, 64..127) or paired (even, odd), see MPC_LANE_PAIR
-    if (line0 < n_lines && qn <= kDeferHigh) lane_fetch<NQ>(va, lines, line0 + (paired ? 2u : 1u) * E.lane, n_lines);
-    while (line0 < n_lines && qn <= kDeferHigh) {
-      const u32 lstep = paired ? 2u : 1u, second = paired ? 1u : 64u;
-      lane_fetch<NQ>(vb, lines, line0 + second + lstep * E.lane, n_lines);
-      const bool full = line0 + 128u <= n_lines;
-      if (full) lane_step<W, OUT, true, false, KINDS...>(va, line0, lstep * E.lane, 0u, true, P, E, rs, qn, alt);
-      else lane_step<W, OUT, false, false, KINDS...>(va, line0, lstep * E.lane, 0u, true, P, E, rs, qn, alt);
-      // the mapping of the next block is fixed here, where its first group is requested
-      if (paired) {
-        if (--pair_left == 0u) paired = false;      // probe with plain groups
-      } else if (alt) {
-        paired = true;
-        pair_left = kPairProbe;
-      }
-      alt = false;
-      lane_fetch<NQ>(va, lines, line0 + stride + (paired ? 2u : 1u) * E.lane, n_lines);
-      if (full) lane_step<W, OUT, true, false, KINDS...>(vb, line0 + second, lstep * E.lane, 0u, true, P, E, rs, qn, alt);
-      else lane_step<W, OUT, false, false, KINDS...>(vb, line0 + second, lstep * E.lane, 0u, true, P, E, rs, qn, alt);
-      line0 += stride;
-      if ((++iter & 127u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
-        lane_run_flush(rs, E.st, E.K, E.bins);
-        rs.cnt = 0;
-        rs.acc_r = 0;
-        rs.acc_r2 = 0;
-      }
+  } else {
+    // ---- streaming through the wave's line ring ----
+    constexpr u32 SB = 64u * 4u * W;                      // bytes of a stage
+    constexpr u32 kNone = 0xffffffffu;
+    const u32 defer_high = E.defer_cap >= 64u ? E.defer_cap - 64u : 0u;
+    const u32 ring_lds = (u32)lane_ring_off(lane_stats_smem(E.K, E.bins) + WPB * E.defer_cap * sizeof(u32)) + wave * (2u * SB);       // two stages per wave
+    u32 lane_off[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) lane_off[j] = ring_src_off<NQ>(j, E.lane);
+    const u32 rd0 = (ring_lds + 16u * NQ * E.lane) | (16u * ring_swz<NQ>(E.lane));      // piece 0 of line `lane` of stage 0 (ring_lds is 1-KiB aligned)
+    // The workgroup owns the blocks [b_begin, b_end) -- a block is 128 consecutive lines, two groups, one per stage --
+    // and its waves draw them one at a time from a counter in LDS.  What is left of the trace behind the last whole
+    // block (fewer than 128 lines) is evaluated from plain loads by one wave of the launch.
+    const u32 n_blocks = n_lines >> 7;
+    const u32 per_wg = uni((n_blocks + gridDim.x - 1u) / gridDim.x);      // (the division runs on the vector unit)
+    const u32 b_begin = blockIdx.x * per_wg;
+    const u32 b_end = b_begin + per_wg < n_blocks ? b_begin + per_wg : n_blocks;
+    u32 *ticket = E.st.hist + E.K * E.bins + 1;
+    auto claim = [&]() -> u32 {
+      u32 t = 0;
+      if (E.lane == 0) t = atomicAdd(ticket, 1u);
+      const u32 blk = b_begin + uni(t);
+      return uni((b_begin < n_blocks && blk < b_end) ? blk : kNone);
+    };
+    // group h (0 / 1) of block blk into stage h
+    auto request = [&](u32 blk, u32 h) { ring_request<NQ>(lane_off, lines + (u64)(2u * blk + h) * (64u * NQ), ring_lds + h * SB); };
+    u32 cb = claim();               // the block whose groups are (being brought) in the stages
+    if (cb != kNone) {
+      request(cb, 0u);
+      request(cb, 1u);
     }
-#else
-    if (line0 < n_lines && qn <= kDeferHigh) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
-    while (line0 < n_lines && qn <= kDeferHigh) {
-      lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
-      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(va, line0, E.lane, 0u, true, P, E, rs, qn, alt);
-      else lane_step<W, OUT, false, false, KINDS...>(va, line0, E.lane, 0u, true, P, E, rs, qn, alt);
-      line0 += stride;
-      if (line0 >= n_lines) break;
-      lane_fetch<NQ>(va, lines, line0 + stride + E.lane, n_lines);
-      if (line0 + 64u <= n_lines) lane_step<W, OUT, true, false, KINDS...>(vb, line0, E.lane, 0u, true, P, E, rs, qn, alt);
-      else lane_step<W, OUT, false, false, KINDS...>(vb, line0, E.lane, 0u, true, P, E, rs, qn, alt);
-      line0 += stride;
-      if ((++iter & 127u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
-        lane_run_flush(rs, E.st, E.K, E.bins);
-        rs.cnt = 0;
-        rs.acc_r = 0;
-        rs.acc_r2 = 0;
+    bool paired = false;            // wave-uniform: this block is evaluated as even lines / odd lines
+    u32 pair_left = 0;
+    bool tail_done = false;
+    for (;;) {
+      while (cb != kNone && qn <= defer_high) {
+        cb = uni(cb);
+        qn = uni(qn);
+        iter = uni(iter);
+        const bool pair_now = uni(paired);
+        const u32 nb = claim();                          // the wave's next block (the counter's latency hides behind the waits)
+        for (u32 h = 0; h < 2u; h = uni(h + 1u)) {
+          // ---- the group's lines: wait for its request, read it out one line per lane, refill what is free ----
+          // (stages are contiguous and hold 64 lines each, so line bl of the block lies at 16 NQ bl; its piece j at
+          // position j ^ f(line): one XOR per piece on the address of piece 0)
+          u32 a0;
+          if (pair_now) {
+            // lane i takes line 2 i + h: both stages are needed before the first group (h = 1: nothing is outstanding)
+            ring_wait_vm<0>();
+            const u32 bl = 2u * E.lane + h;
+            a0 = (ring_lds + 16u * NQ * bl) | (16u * ring_swz<NQ>(bl & 63u));
+          } else {
+            // requests complete in issue order (stage 0, then stage 1): the wanted one has landed when at most the NQ
+            // instructions of the one request issued after it are outstanding
+            if (uni(h == 0u || nb != kNone)) ring_wait_vm<NQ>();
+            else ring_wait_vm<0>();
+            a0 = rd0 + h * SB;
+          }
+          u32 a[NQ];
+#pragma unroll
+          for (int j = 0; j < NQ; j++) a[j] = a0 ^ (16u * (u32)j);
+          ring_read<NQ>(va, a);
+          if constexpr (!(MPC_ABLATE & 32)) {                             // (timing ablation 32: stale lines are evaluated)
+            if (nb != kNone) {
+              if (!pair_now) {
+                request(nb, h);                                           // stage h is free
+              } else if (h == 1u) {                                       // both stages are free
+                request(nb, 0u);
+                request(nb, 1u);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);                              // (the requests go out before the arithmetic, not after it)
+          // (one call site: the group code is large)
+          lane_step<W, OUT, true, false, KINDS...>(va, pair_now ? cb * 128u + h : cb * 128u + h * 64u, pair_now ? 2u * E.lane : E.lane,
+                                                   0u, true, P, E, rs, qn, alt);
+          if ((++iter & 255u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
+            lane_run_flush(rs, E.st, E.K, E.bins);
+            rs.cnt = 0;
+            rs.acc_r = 0;
+            rs.acc_r2 = 0;
+          }
+        }
+        // how the next block is evaluated
+        alt = uni(alt);
+        paired = uni(paired);
+        pair_left = uni(pair_left);
+        if (paired) {
+          if (--pair_left == 0u) paired = false;       // probe with plain groups
+        } else if (alt) {
+          paired = true;
+          pair_left = kPairProbe;
+        }
+        alt = false;
+        cb = nb;
       }
+      // the lines behind the launch's last whole block (fewer than 128): plain loads, by one wave of the launch
+      if (!tail_done && cb == kNone && blockIdx.x == gridDim.x - 1u && wave == 0u && qn <= defer_high) {
+        for (u32 l0 = n_blocks * 128u; l0 < n_lines; l0 += 64u) {
+          lane_fetch<NQ>(va, lines, l0 + E.lane, n_lines);
+          lane_step<W, OUT, false, false, KINDS...>(va, l0, E.lane, 0u, true, P, E, rs, qn, alt);
+        }
+        tail_done = true;
+      }
+      // ---- drain: the queued lines, 64 at a time from the top of the queue ----
+      while (qn > 0u) {
+        const u32 take = qn < 64u ? qn : 64u;
+        qn -= take;
+        const bool dvalid = E.lane < take;
+        const u32 dline = dvalid ? E.defer_q[qn + E.lane] : 0u;
+        lane_fetch<NQ>(va, lines, dline, n_lines);
+        lane_step<W, OUT, false, true, KINDS...>(va, 0u, 0u, dline, dvalid, P, E, rs, qn, alt);
+      }
+      if (cb == kNone && (tail_done || blockIdx.x != gridDim.x - 1u || wave != 0u)) break;
     }
-#endif
-    // ---- drain: the queued lines, 64 at a time from the top of the queue ----
-    while (qn > 0u) {
-      const u32 take = qn < 64u ? qn : 64u;
-      qn -= take;
-      const bool dvalid = E.lane < take;
-      const u32 dline = dvalid ? E.defer_q[qn + E.lane] : 0u;
-      lane_fetch<NQ>(va, lines, dline, n_lines);
-      lane_step<W, OUT, false, true, KINDS...>(va, 0u, 0u, dline, dvalid, P, E, rs, qn, alt);
-    }
-    if (line0 >= n_lines) break;
   }
   lane_run_flush(rs, E.st, E.K, E.bins);
   stats_flush(E.st, E.K, E.bins, gstats);
@@ -1046,23 +1245,44 @@ bool lane_seq_matches(const MpcVpcParams *P)
 
 template <int... KINDS>
 hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpcParams *P, uint16_t *d_sizes,
-                       int8_t *d_sel, u64 *d_stats, int grid, size_t smem, hipStream_t stream)
+                       int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
 {
   // OUT = per-line outputs requested (parity mode); the statistics-only build has no output code
   // histograms of many clusters x bins need more than the 64 KiB of LDS a kernel gets by default
 #define MPC_LAUNCH(WV)                                                                                              \
-  if (d_sizes || d_sel) {                                                                                          \
-    if (smem > (64u << 10))                                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_lane_kernel<WV, true, KINDS...>),              \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                            \
-    hipLaunchKernelGGL((vpc_lane_kernel<WV, true, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines,     \
-                       first_line, *P, d_sizes, d_sel, d_stats);                                                   \
-  } else {                                                                                                         \
-    if (smem > (64u << 10))                                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_lane_kernel<WV, false, KINDS...>),             \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                            \
-    hipLaunchKernelGGL((vpc_lane_kernel<WV, false, KINDS...>), dim3(grid), dim3(256), smem, stream, l, n_lines,    \
-                       first_line, *P, d_sizes, d_sel, d_stats);                                                   \
+  {                                                                                                                \
+    constexpr int wpb = lane_wpb<WV, sizeof...(KINDS)>();                                                          \
+    size_t smem;                                                                                                   \
+    u32 ring_cfg = 0;                                                                                              \
+    int wgrid;                                                                                                     \
+    if (sizeof...(KINDS) == 0) {                                                                                   \
+      smem = lane_stats_smem(P->M + 1, P->hist_bins);                                                              \
+      wgrid = grid;                                                                                                \
+    } else {                                                                                                       \
+      const LaneLds plan = lane_lds_plan(P, wpb, WV <= 16);                                                        \
+      if (plan.stages == 0) return hipErrorInvalidConfiguration;      /* (mpc_vpc_lane_unrolled said no) */        \
+      smem = plan.bytes;                                                                                           \
+      ring_cfg = plan.stages | (plan.cap << 8);                                                                    \
+      /* `grid` counts 256-thread workgroups, 32 per CU when the trace is long: two large workgroups per CU */     \
+      /* (four of 512 threads), one resident; never more than one block of lines per wave would fill */           \
+      const u64 want = (n_lines / 64u + (u64)wpb - 1u) / (u64)wpb;                                                 \
+      const u64 cap = (u64)grid / (wpb == 16 ? 16u : 8u);                                                          \
+      wgrid = (int)(want < cap ? want : cap);                                                                      \
+      if (wgrid < 1) wgrid = 1;                                                                                    \
+    }                                                                                                              \
+    if (d_sizes || d_sel) {                                                                                        \
+      if (smem > (64u << 10))                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_lane_kernel<WV, true, KINDS...>),            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
+      hipLaunchKernelGGL((vpc_lane_kernel<WV, true, KINDS...>), dim3(wgrid), dim3(64 * wpb), smem, stream, l,      \
+                         n_lines, first_line, *P, d_sizes, d_sel, d_stats, ring_cfg);                              \
+    } else {                                                                                                       \
+      if (smem > (64u << 10))                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_lane_kernel<WV, false, KINDS...>),           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
+      hipLaunchKernelGGL((vpc_lane_kernel<WV, false, KINDS...>), dim3(wgrid), dim3(64 * wpb), smem, stream, l,     \
+                         n_lines, first_line, *P, d_sizes, d_sel, d_stats, ring_cfg);                              \
+    }                                                                                                              \
   }
   switch (P->L) {
 #if defined(MPC_LANE_W)    // one line size per translation unit (parallel build, see the end of this file)
@@ -1097,6 +1317,20 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
   X(DF, DF, DFP, CS, WTQ) X(DFQ) X(WTQ)
 #endif
 
+// the line sizes this translation unit holds kernels for
+static bool lane_has_line_size(int L)
+{
+#if defined(MPC_LANE_W)
+  return L == 4 * MPC_LANE_W;
+#elif defined(MPC_DEV_ONLY64) && defined(MPC_DEV_ALSO128)
+  return L == 64 || L == 128;
+#elif defined(MPC_DEV_ONLY64)
+  return L == 64;
+#else
+  return L == 32 || L == 64 || L == 128;
+#endif
+}
+
 }  // namespace
 
 // Build layout.  Compiled as it is, this file holds every line size (development builds).  The product build
@@ -1106,17 +1340,24 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
 #define MPC_CAT(a, b) MPC_CAT2(a, b)
 
 #if !defined(MPC_LANE_W) || MPC_LANE_W == 0
-// 1 when the module sequence has an unrolled instantiation (else the run-time loop runs it)
+// 1 when the module sequence has an unrolled instantiation whose rings fit the LDS (else the run-time loop runs it)
 extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P)
 {
+  const int wpb = P->L <= 64 ? MPC_LANE_WAVES : MPC_LANE_WAVES_128;
+  if (lane_lds_plan(P, wpb, P->L <= 64).stages == 0) return 0;
 #define X(...) if (lane_seq_matches<__VA_ARGS__>(P)) return 1;
   MPC_LANE_SEQUENCES(X)
 #undef X
   return 0;
 }
 
-// statistics + the four waves' queues of deferred lines
-extern "C" size_t mpc_vpc_lane_smem(const MpcVpcParams *P) { return lane_stats_smem(P->M + 1, P->hist_bins) + 4u * kDeferCap * sizeof(u32); }
+// dynamic LDS of a launch (the host checks it against the 160 KiB of a CU when a handle is created)
+extern "C" size_t mpc_vpc_lane_smem(const MpcVpcParams *P)
+{
+  if (!mpc_vpc_lane_unrolled(P)) return lane_stats_smem(P->M + 1, P->hist_bins);
+  const int wpb = P->L <= 64 ? MPC_LANE_WAVES : MPC_LANE_WAVES_128;
+  return lane_lds_plan(P, wpb, P->L <= 64).bytes;
+}
 #endif
 
 #if defined(MPC_LANE_W) && MPC_LANE_W == 0
@@ -1143,21 +1384,24 @@ extern "C" hipError_t mpc_launch_vpc_lane(const void *d_lines, u64 n_lines, cons
 extern "C" hipError_t MPC_LAUNCH_NAME(const void *d_lines, u64 n_lines, const MpcVpcParams *P, uint16_t *d_sizes,
                                       int8_t *d_sel, u64 *d_stats, int grid, hipStream_t stream)
 {
-  const size_t smem = lane_stats_smem(P->M + 1, P->hist_bins) + 4u * kDeferCap * sizeof(u32);
+  if (!lane_has_line_size(P->L)) return hipErrorInvalidValue;
   const u64 max_lines = 1ull << 30;     // 32-bit line indices inside the kernel
+  // a sequence whose rings do not fit the LDS beside its histogram runs the run-time module loop
+  const int wpb = P->L <= 64 ? MPC_LANE_WAVES : MPC_LANE_WAVES_128;
+  const bool rings_fit = lane_lds_plan(P, wpb, P->L <= 64).stages != 0;
   for (u64 done = 0; done < n_lines; done += max_lines) {
     const u64 take = (n_lines - done) < max_lines ? (n_lines - done) : max_lines;
     const uint4 *l = static_cast<const uint4 *>(d_lines) + done * (u64)(P->L / 16);
     hipError_t e = hipErrorInvalidValue;
     bool launched = false;
 #define X(...)                                                                                                     \
-    if (!launched && lane_seq_matches<__VA_ARGS__>(P)) {                                                           \
-      e = lane_launch<__VA_ARGS__>(l, (u32)take, done, P, d_sizes, d_sel, d_stats, grid, smem, stream);            \
+    if (!launched && rings_fit && lane_seq_matches<__VA_ARGS__>(P)) {                                              \
+      e = lane_launch<__VA_ARGS__>(l, (u32)take, done, P, d_sizes, d_sel, d_stats, grid, stream);                  \
       launched = true;                                                                                             \
     }
     MPC_LANE_SEQUENCES(X)
 #undef X
-    if (!launched) e = lane_launch<>(l, (u32)take, done, P, d_sizes, d_sel, d_stats, grid, smem, stream);   // run-time sequence
+    if (!launched) e = lane_launch<>(l, (u32)take, done, P, d_sizes, d_sel, d_stats, grid, stream);   // run-time sequence
     if (e != hipSuccess) return e;
   }
   return hipSuccess;

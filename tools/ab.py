@@ -56,6 +56,12 @@ if os.environ.get("AB_CHECK") == "1":
         o = O.VpcOracle(configs.probe_config(64)); s_ref, k_ref = o.compress(lines)
         s, k = ev.compress_lines(lines)
         ok = bool((s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all())
+        # lines of two kinds alternating (paired groups), in trace order, with a ragged end
+        alt = np.concatenate([traces.mixed(20000), traces.random_u32(777), traces.mixed(5001, first_line=3)])
+        ev.reset(); o.reset()
+        s_ref, k_ref = o.compress(alt)
+        s, k = ev.compress_lines(alt)
+        ok = ok and bool((s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all())
     else:
         o = {"BDI": O.BdiOracle, "FPC": O.FpcOracle, "BPC": O.BpcOracle}[algo](64)
         r = o.compress(lines); s_ref = r[0] if isinstance(r, tuple) else r
@@ -67,7 +73,7 @@ W = {"random_u32": ("random_u32", 64), "sine_f32": ("sine_f32", 64), "mixed": ("
      "pointers_u64_128": ("pointers_u64", 128)}
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
-for w in workloads:
+for w in [x for x in workloads if x]:
     kind, L = W[w]
     buf = torch.empty(n * L, dtype=torch.uint8, device=dev)
     mpc.synth_fill(buf.data_ptr(), n, L, kind, first_line=0)
@@ -105,11 +111,20 @@ def run(args):
             so = os.path.join(OUT, f"libmpc_hip_{name}.so") if name != "tree" else os.path.join(ROOT, "cal_22-mpc_amd", "libmpc_hip.so")
             env = dict(os.environ, MPC_HIP_LIB=so, MPC_ROOT=ROOT, AB_NAME=name, AB_ALGO=algo, AB_WORKLOADS=workloads,
                        AB_LINES=str(lines), AB_STEPS=str(steps), AB_CHECK="1" if r == 0 else "0")
+            if r == 0:
+                # parity once more with the grid capped to 3 workgroups (a wave then walks many groups of lines: ring
+                # stages are reused, queues fill and drain), in a process of its own: the cap is read once per process
+                cenv = dict(env, AB_WORKLOADS="", MPC_TEST_GRID="3")
+                cp = subprocess.run([sys.executable, "-c", CHILD], env=cenv, capture_output=True, text=True)
+                cl = [l for l in cp.stdout.split("\n") if l.startswith("AB ")]
+                if not cl or not json.loads(cl[-1][3:]).get("parity"):
+                    print(f"{name}: parity with a capped grid FAILED\n{cp.stdout[-1500:]}\n{cp.stderr[-1500:]}", flush=True)
+                    raise SystemExit(3)
             p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
             line = [l for l in p.stdout.split("\n") if l.startswith("AB ")]
             if not line:
                 print(f"{name} round {r}: FAILED\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}", flush=True)
-                continue
+                raise SystemExit(3)          # a variant that crashed may have faulted on the GPU: no further GPU step in this call
             d = json.loads(line[-1][3:])
             table.setdefault(name, []).append(d)
             print(f"round {r} {name:>12}: " + ("" if "parity" not in d else f"parity={'ok' if d['parity'] else 'FAIL'} ") +
