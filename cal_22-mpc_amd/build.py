@@ -14,6 +14,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
 LIB = os.path.join(HERE, "libmpc_hip.so")
+TEST_LIB = os.path.join(HERE, "libmpc_hip_test.so")      # -DMPC_TESTING=1: route counters + MPC_TEST_GRID (tests only)
 CLI = os.path.join(ROOT, "bin", "compressor")
 
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -37,20 +38,23 @@ def _sources(d: str):
     return out
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    """libmpc_hip.so.  The translation units are compiled in parallel: the lane kernel file once per line size
-    (-DMPC_LANE_W=8/16/32) plus its dispatcher (-DMPC_LANE_W=0), the other kernels, the C ABI; then linked."""
+def build_lib(force: bool = False, verbose: bool = False, test: bool = False) -> str:
+    """libmpc_hip.so (test=True: libmpc_hip_test.so, the same sources with -DMPC_TESTING=1).  The translation units
+    are compiled in parallel: the lane kernel file once per line size (-DMPC_LANE_W=8/16/32) plus its dispatcher
+    (-DMPC_LANE_W=0), the other kernels, the C ABI; then linked."""
+    LIB = TEST_LIB if test else globals()["LIB"]
     deps = _sources(CSRC) + [os.path.join(ROOT, "include", "mpc_hip.h")]
     if not force and _newer(LIB, deps):
         return LIB
-    objdir = os.path.join(HERE, "obj")
+    objdir = os.path.join(HERE, "obj_test" if test else "obj")
     os.makedirs(objdir, exist_ok=True)
     lane = os.path.join(CSRC, "mpc_vpc_lane.hip")
     units = [(lane, f"lane_w{w}.o", [f"-DMPC_LANE_W={w}"]) for w in (16, 32, 8, 0)]
     units += [(os.path.join(CSRC, "mpc_kernels.hip"), "kernels.o", []), (os.path.join(CSRC, "mpc_capi.hip"), "capi.o", [])]
+    tflag = ["-DMPC_TESTING=1"] if test else []
     procs = []
     for src, obj, extra in units:
-        cmd = [HIPCC, *FLAGS, *extra, "-c", src, "-o", os.path.join(objdir, obj)]
+        cmd = [HIPCC, *FLAGS, *tflag, *extra, "-c", src, "-o", os.path.join(objdir, obj)]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -83,6 +87,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
 
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_lib(force, verbose)
+    build_lib(force, verbose, test=True)
     build_cli(force, verbose)
 
 

@@ -22,6 +22,13 @@
 #include "mpc_config.h"
 #include "mpc_device.h"
 
+// libmpc_hip_test.so (build.py, -DMPC_TESTING=1): route counters behind the raw statistics and a cap on the launch grid,
+// see mpc_kernel_common.h.  Must agree with the kernels' translation units.
+#ifndef MPC_TESTING
+#define MPC_TESTING 0
+#endif
+constexpr size_t kRouteWords = MPC_TESTING ? 16 : 0;
+
 typedef unsigned long long u64;
 
 extern "C" {
@@ -128,9 +135,9 @@ int finish_create(mpc_handle *h)
 {
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
     return set_err(nullptr, MPC_E_NODEVICE, "hipStreamCreate failed");
-  if (hipMalloc(&h->d_raw, h->raw_len * sizeof(u64)) != hipSuccess)
+  if (hipMalloc(&h->d_raw, (h->raw_len + kRouteWords) * sizeof(u64)) != hipSuccess)
     return set_err(nullptr, MPC_E_NOMEM, "hipMalloc(stats) failed");
-  if (hipMemsetAsync(h->d_raw, 0, h->raw_len * sizeof(u64), h->stream) != hipSuccess ||
+  if (hipMemsetAsync(h->d_raw, 0, (h->raw_len + kRouteWords) * sizeof(u64), h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess)
     return set_err(nullptr, MPC_E_NODEVICE, "hipMemset(stats) failed");
   h->extra.assign(h->stats_len, 0);
@@ -244,10 +251,12 @@ int grid_for(const mpc_handle *h, u64 work_items, int block, int per_cu)
 {
   u64 need = (work_items + (u64)block - 1) / (u64)block;
   u64 cap = (u64)h->num_cus * (u64)per_cu;
-  // tests only: MPC_TEST_GRID caps the grid so that a wave walks many groups of lines (the kernels' deferred-line
+#if MPC_TESTING
+  // test library only: MPC_TEST_GRID caps the grid so that a wave walks many groups of lines (the kernels' deferred-line
   // queues then fill and drain inside the loop even on small inputs)
   static const long test_cap = []() { const char *e = getenv("MPC_TEST_GRID"); return e ? atol(e) : 0L; }();
   if (test_cap > 0 && cap > (u64)test_cap) cap = (u64)test_cap;
+#endif
   if (need < 1) need = 1;
   return (int)(need < cap ? need : cap);
 }
@@ -921,7 +930,7 @@ int mpc_stats_reset(mpc_handle *h)
   int rc = sync_all(h);
   if (rc != MPC_OK) return rc;
   HIPCHK(h, hipDeviceSynchronize());
-  HIPCHK(h, hipMemset(h->d_raw, 0, h->raw_len * sizeof(u64)));
+  HIPCHK(h, hipMemset(h->d_raw, 0, (h->raw_len + kRouteWords) * sizeof(u64)));
   h->extra.assign(h->stats_len, 0);
   return MPC_OK;
 }
@@ -997,5 +1006,20 @@ int mpc_read_bandwidth_probe(const void *d_buf, uint64_t bytes, void *stream)
   hipError_t e = mpc_launch_read_probe(d_buf, bytes, sink[dev], 256 * 8, (hipStream_t)stream);
   return e == hipSuccess ? MPC_OK : MPC_E_HIP;
 }
+
+#if MPC_TESTING
+// test library only (not part of include/mpc_hip.h): the kernels' route counters since the handle was created or
+// its statistics were last reset; out[i] for i < n, order of the MPC_RT_* enumeration (mpc_kernel_common.h)
+int mpc_test_routes(mpc_handle *h, uint64_t *out, size_t n)
+{
+  if (!h || !out) return MPC_E_INVAL;
+  if (hipSetDevice(h->device) != hipSuccess) return MPC_E_HIP;
+  HIPCHK(h, hipDeviceSynchronize());
+  uint64_t tmp[kRouteWords];
+  HIPCHK(h, hipMemcpy(tmp, h->d_raw + h->raw_len, sizeof(tmp), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; i++) out[i] = i < kRouteWords ? tmp[i] : 0;
+  return MPC_OK;
+}
+#endif
 
 }  // extern "C"

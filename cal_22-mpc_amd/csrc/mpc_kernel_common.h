@@ -9,6 +9,38 @@
 typedef unsigned long long u64;
 typedef uint32_t u32;
 
+// ---------------------------------------------------------------------------
+// MPC_TESTING (libmpc_hip_test.so only, cal_22-mpc_amd/build.py): the kernels count how often their alternative
+// routes ran -- lines set aside into the LDS queues, drain groups, paired / plain blocks, switches between the two --
+// in MPC_ROUTE_COUNT extra words behind the raw statistics of the handle, which mpc_test_routes() (test library
+// only) reads; and the launch grid can be capped with the MPC_TEST_GRID environment variable.  The product library
+// has neither: the counting code is compiled out and the variable is not read.
+// ---------------------------------------------------------------------------
+#ifndef MPC_TESTING
+#define MPC_TESTING 0
+#endif
+enum {
+  MPC_RT_VPC_DEFERRED = 0,   // lines set aside into a wave's queue
+  MPC_RT_VPC_DRAINS,         // drain groups (up to 64 queued lines each)
+  MPC_RT_VPC_PAIRED_BLOCKS,  // 128-line blocks evaluated as even lines / odd lines
+  MPC_RT_VPC_PLAIN_BLOCKS,   // 128-line blocks evaluated as first half / second half
+  MPC_RT_VPC_TO_PAIRED,      // a wave switched from plain to paired groups
+  MPC_RT_VPC_TO_PLAIN,       // a wave went back to plain groups to probe
+  MPC_RT_VPC_TAIL_GROUPS,    // groups behind the last whole block (plain loads)
+  MPC_RT_BDI_DEFERRED,
+  MPC_RT_BDI_DRAINS,
+  MPC_ROUTE_COUNT = 16
+};
+// called by ONE lane of a wave
+__device__ __forceinline__ void route_add(u64 *routes, int which, u32 v)
+{
+#if MPC_TESTING
+  if (v) atomicAdd(&routes[which], (u64)v);
+#else
+  (void)routes; (void)which; (void)v;
+#endif
+}
+
 #define H80 0x80808080u
 #define L7F 0x7f7f7f7fu
 

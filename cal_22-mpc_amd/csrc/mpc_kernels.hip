@@ -542,6 +542,10 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
     while (qn > 0u) {
       const u32 take = qn < 64u ? qn : 64u;
       qn -= take;
+      if (MPC_TESTING && lane == 0) {      // (test library only: route counters behind the statistics)
+        route_add(gstats + MPC_BDI_RAW_LEN, MPC_RT_BDI_DRAINS, 1u);
+        route_add(gstats + MPC_BDI_RAW_LEN, MPC_RT_BDI_DEFERRED, take);
+      }
       const bool active = lane < take;
       const u64 line = active ? (u64)queue[qn + lane] : 0ull;
       u32 w[NW];

@@ -1079,6 +1079,8 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
   LaneRun rs = {0xffffffffu, 0, 0, 0, false};
   u32 iter = 0;
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u64 *routes = gstats + (2 * E.K + E.K * E.bins);         // (test library only: route counters behind the raw statistics)
+  (void)routes;
   bool alt = false;    // wave-uniform: the prefilters saw lines of two kinds alternate (paired groups)
   uint4 va[NQ];
   u32 qn = 0;          // deferred lines waiting in the wave's queue (wave-uniform)
@@ -1189,11 +1191,16 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
         alt = uni(alt);
         paired = uni(paired);
         pair_left = uni(pair_left);
+        if (MPC_TESTING && E.lane == 0) route_add(routes, pair_now ? MPC_RT_VPC_PAIRED_BLOCKS : MPC_RT_VPC_PLAIN_BLOCKS, 1u);
         if (paired) {
-          if (--pair_left == 0u) paired = false;       // probe with plain groups
+          if (--pair_left == 0u) {                     // probe with plain groups
+            paired = false;
+            if (MPC_TESTING && E.lane == 0) route_add(routes, MPC_RT_VPC_TO_PLAIN, 1u);
+          }
         } else if (alt) {
           paired = true;
           pair_left = kPairProbe;
+          if (MPC_TESTING && E.lane == 0) route_add(routes, MPC_RT_VPC_TO_PAIRED, 1u);
         }
         alt = false;
         cb = nb;
@@ -1203,6 +1210,7 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
         for (u32 l0 = n_blocks * 128u; l0 < n_lines; l0 += 64u) {
           lane_fetch<NQ>(va, lines, l0 + E.lane, n_lines);
           lane_step<W, OUT, false, false, KINDS...>(va, l0, E.lane, 0u, true, P, E, rs, qn, alt);
+          if (MPC_TESTING && E.lane == 0) route_add(routes, MPC_RT_VPC_TAIL_GROUPS, 1u);
         }
         tail_done = true;
       }
@@ -1210,6 +1218,10 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
       while (qn > 0u) {
         const u32 take = qn < 64u ? qn : 64u;
         qn -= take;
+        if (MPC_TESTING && E.lane == 0) {
+          route_add(routes, MPC_RT_VPC_DRAINS, 1u);
+          route_add(routes, MPC_RT_VPC_DEFERRED, take);
+        }
         const bool dvalid = E.lane < take;
         const u32 dline = dvalid ? E.defer_q[qn + E.lane] : 0u;
         lane_fetch<NQ>(va, lines, dline, n_lines);

@@ -766,70 +766,106 @@ def test_bench_two_rank_rehearsal_child_process():
     assert c4["compression_ratio"] > 1.0
 
 
-def test_deferred_line_queues_fill_and_drain_inside_the_loop(oracle, configs, traces, tmp_path):
-    """The VPC and BDI kernels set lines aside into per-wave LDS queues (a few hundred entries) and drain them when
-    the queue is nearly full.  With the grid capped to two workgroups (MPC_TEST_GRID, tests only) every wave walks
-    hundreds of groups of lines, so the queues fill and drain many times inside the loop; results against the
-    oracle, in a fresh process (the cap is read once per process)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r"""
-import importlib, sys
+ROUTE_NAMES = ["vpc_deferred", "vpc_drains", "vpc_paired_blocks", "vpc_plain_blocks", "vpc_to_paired", "vpc_to_plain",
+               "vpc_tail_groups", "bdi_deferred", "bdi_drains"]        # MPC_RT_* of csrc/mpc_kernel_common.h
+
+ROUTES_PRELUDE = r"""
+import ctypes, importlib, json, sys
 import numpy as np
 sys.path.insert(0, %r)
 mpc = importlib.import_module("cal_22-mpc_amd"); C = importlib.import_module("cal_22-mpc_amd.configs"); T = importlib.import_module("cal_22-mpc_amd.traces")
 from oracle import oracle as O
+assert mpc.LIB_PATH.endswith("libmpc_hip_test.so"), mpc.LIB_PATH
+def routes(ev):
+    # test library only: how often the kernels' alternative routes ran since the statistics were last reset
+    f = mpc.lib().mpc_test_routes
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]; f.restype = ctypes.c_int
+    out = (ctypes.c_uint64 * 16)()
+    assert f(ev._h, out, 16) == 0
+    return dict(zip(%r, [int(x) for x in out]))
+"""
+
+
+def _run_with_test_library(code: str, grid_cap: int, timeout: int = 900):
+    """A fresh process bound to libmpc_hip_test.so (the product library has neither route counters nor the grid
+    cap), MPC_TEST_GRID set; returns the JSON object the code printed behind 'ROUTES '."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    test_lib = os.path.join(root, "cal_22-mpc_amd", "libmpc_hip_test.so")
+    assert os.path.exists(test_lib), "libmpc_hip_test.so is missing: python cal_22-mpc_amd/build.py"
+    env = dict(os.environ, MPC_TEST_GRID=str(grid_cap), MPC_HIP_LIB=test_lib)
+    r = subprocess.run([sys.executable, "-c", (ROUTES_PRELUDE % (root, ROUTE_NAMES)) + code], capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.split("\n") if l.startswith("ROUTES ")]
+    assert line, r.stdout[-2000:]
+    return json.loads(line[-1][7:])
+
+
+def test_deferred_line_queues_fill_and_drain_inside_the_loop(oracle, configs, traces, tmp_path):
+    """The VPC and BDI kernels set lines aside into per-wave LDS queues (a few hundred entries) and drain them when
+    the queue is nearly full.  With the grid capped (MPC_TEST_GRID, test library only) every wave walks hundreds of
+    groups of lines, so the queues fill and drain many times inside the loop; results against the oracle, in a fresh
+    process (the cap is read once per process).  The test library's route counters say that lines really were set
+    aside and that drains really ran inside the loop, not only at its end."""
+    code = r"""
 lines = np.concatenate([T.mixed(90000, 64), T.structured(60000, 64, seed=3), T.sine_f32(20000, 64), T.bdi_screen_stress(48000, 64),
                         T.random_u32(30001, 64)])
 lines = lines[np.random.default_rng(7).permutation(len(lines))]
-for cfg in (C.probe_config(64), C.mpc_config(64)):
+res = {}
+for name, cfg in (("probe", C.probe_config(64)), ("mpc", C.mpc_config(64))):
     ev, o = mpc.VPC(cfg), O.VpcOracle(cfg)
     s, k = ev.compress_lines(lines)
     s_ref, k_ref = o.compress(lines)
     assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all()
+    res[name] = routes(ev)
 ev, o = mpc.BDI(64), O.BdiOracle(64)
 s, k = ev.compress_lines(lines)
 s_ref, k_ref = o.compress(lines)
 assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all()
-print("queues ok", len(lines))
-""" % root
-    env = dict(os.environ, MPC_TEST_GRID="2")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert r.returncode == 0 and "queues ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+res["bdi"] = routes(ev)
+print("ROUTES " + json.dumps(res))
+"""
+    res = _run_with_test_library(code, grid_cap=2)          # one large workgroup of the VPC lane kernel (16 waves); 8 waves for BDI
+    for name in ("probe", "mpc"):
+        r = res[name]
+        # a wave's end-of-trace drain is at most 256 / 64 = 4 groups: more than 16 x 4 drain groups means that queues
+        # were drained inside the streaming loop
+        assert r["vpc_deferred"] > 0 and r["vpc_drains"] > 64, (name, r)
+        assert r["vpc_deferred"] <= 64 * r["vpc_drains"], (name, r)
+    b = res["bdi"]
+    # 8 waves, 512 entries each: more than 8 x 8 drain groups cannot come from the end of the trace alone
+    assert b["bdi_deferred"] > 0 and b["bdi_drains"] > 64 and b["bdi_deferred"] <= 64 * b["bdi_drains"], b
 
 
 def test_paired_groups_on_alternating_lines(oracle, configs, traces, tmp_path):
     """Where neighbouring lines alternate between two kinds the VPC lane kernel switches a wave to paired groups
     (even lines of a 128-line block, then the odd ones) and probes with plain groups now and then.  With the grid
-    capped to one workgroup (MPC_TEST_GRID, tests only) every wave walks hundreds of blocks, so it switches back and forth; traces
-    that alternate throughout, that alternate in stretches between other data, and that end inside a block;
-    per-line results and statistics against the oracle, in a fresh process (the cap is read once per process)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    capped to one workgroup (MPC_TEST_GRID, test library only) every wave walks hundreds of blocks, so it switches back
+    and forth; traces that alternate throughout, that alternate in stretches between other data, and that end inside
+    a block; per-line results and statistics against the oracle, in a fresh process (the cap is read once per
+    process).  The test library's route counters say that paired blocks were evaluated, that waves went paired ->
+    plain (probe) -> paired again, and that non-alternating data stayed plain."""
     code = r"""
-import importlib, sys
-import numpy as np
-sys.path.insert(0, %r)
-mpc = importlib.import_module("cal_22-mpc_amd"); C = importlib.import_module("cal_22-mpc_amd.configs"); T = importlib.import_module("cal_22-mpc_amd.traces")
-from oracle import oracle as O
+res = {}
 for L, n in ((64, 150001), (32, 60037), (128, 50003)):
     alt = T.mixed(n, L)
     parts = [T.mixed(20000 + 77, L), T.random_u32(9000 + 5, L), T.mixed(30001, L, first_line=1), T.structured(12000, L, seed=3),
              T.mixed(8192, L), T.zeros(300, L), T.mixed(4097, L)]
-    for lines in (alt, np.concatenate(parts)):
-        for cfg in (C.probe_config(L), C.mpc_config(L)):
+    for tname, lines in (("alt", alt), ("parts", np.concatenate(parts)), ("random", T.random_u32(40000, L))):
+        for cname, cfg in (("probe", C.probe_config(L)), ("mpc", C.mpc_config(L))):
             ev, o = mpc.VPC(cfg), O.VpcOracle(cfg)
             s, k = ev.compress_lines(lines)
             s_ref, k_ref = o.compress(lines)
             assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all(), (L, len(lines))
+            res["%d/%s/%s" % (L, tname, cname)] = routes(ev)
             ev.close()
 # the reference-derived whole-line vectors of the interleaved trace (tests/golden/ref_line_vectors.json: numbers of
 # the reference's compiled stage classes), now evaluated in paired groups
-sys.path.insert(0, %r)
+sys.path.insert(0, "tests")
 import ref_lines
 n_ref = 0
 for name, cfg, lines, c in ref_lines.load_cases():
@@ -842,8 +878,24 @@ for name, cfg, lines, c in ref_lines.load_cases():
     ev.close()
     n_ref += 1
 assert n_ref >= 2
-print("paired ok")
-""" % (root, os.path.join(root, "tests"))
-    env = dict(os.environ, MPC_TEST_GRID="1")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert r.returncode == 0 and "paired ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+print("ROUTES " + json.dumps(res))
+"""
+    res = _run_with_test_library(code, grid_cap=1)
+    for key, r in res.items():
+        L, tname, cname = key.split("/")
+        blocks = r["vpc_paired_blocks"] + r["vpc_plain_blocks"]
+        if cname == "mpc" and blocks == 0:
+            continue                  # (a configuration that runs the run-time module loop: no ring, no blocks)
+        assert blocks > 0, (key, r)
+        if tname == "random":
+            assert r["vpc_paired_blocks"] == 0 and r["vpc_to_paired"] == 0, (key, r)
+        elif cname == "probe":
+            # the probe configuration's modules tell the two kinds of line apart: most blocks of the alternating trace
+            # are paired, and every wave that stayed long enough probed with plain groups and came back
+            assert r["vpc_paired_blocks"] > 0 and r["vpc_to_paired"] > 0, (key, r)
+            if tname == "alt" and L != "128":
+                assert r["vpc_paired_blocks"] > r["vpc_plain_blocks"], (key, r)
+            if tname == "alt" and L == "64":
+                # 1171 blocks over 16 waves: every wave passes the probe interval (64 paired blocks) once,
+                # goes back to plain groups and returns to paired ones
+                assert r["vpc_to_plain"] >= 8 and r["vpc_to_paired"] > r["vpc_to_plain"], (key, r)

@@ -25,10 +25,12 @@ def build(specs):
         name, _, flags = spec.partition("=")
         name, _, src = name.partition("@")          # NAME@DIR: sources from another csrc directory (a saved baseline)
         csrc = os.path.abspath(src) if src else CSRC
-        so = os.path.join(OUT, f"libmpc_hip_{name}.so")
-        cmd = ["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DMPC_DEV_ONLY64", *flags.split(),
-               "-shared", "-o", so] + [os.path.join(csrc, f) for f in ("mpc_vpc_lane.hip", "mpc_kernels.hip", "mpc_capi.hip")]
-        procs.append((name, subprocess.Popen(cmd)))
+        # NAME: the timed library; NAME_t: the same with -DMPC_TESTING=1 (honours MPC_TEST_GRID) for the capped-grid parity check
+        for suffix, extra in (("", []), ("_t", ["-DMPC_TESTING=1"])):
+            so = os.path.join(OUT, f"libmpc_hip_{name}{suffix}.so")
+            cmd = ["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DMPC_DEV_ONLY64", *flags.split(), *extra,
+                   "-shared", "-o", so] + [os.path.join(csrc, f) for f in ("mpc_vpc_lane.hip", "mpc_kernels.hip", "mpc_capi.hip")]
+            procs.append((name + suffix, subprocess.Popen(cmd)))
     bad = [n for n, p in procs if p.wait() != 0]
     if bad:
         raise SystemExit(f"build failed: {bad}")
@@ -114,7 +116,8 @@ def run(args):
             if r == 0:
                 # parity once more with the grid capped to 3 workgroups (a wave then walks many groups of lines: ring
                 # stages are reused, queues fill and drain), in a process of its own: the cap is read once per process
-                cenv = dict(env, AB_WORKLOADS="", MPC_TEST_GRID="3")
+                so_t = so[:-3] + "_t.so"
+                cenv = dict(env, AB_WORKLOADS="", MPC_TEST_GRID="3", MPC_HIP_LIB=so_t if os.path.exists(so_t) else so)
                 cp = subprocess.run([sys.executable, "-c", CHILD], env=cenv, capture_output=True, text=True)
                 cl = [l for l in cp.stdout.split("\n") if l.startswith("AB ")]
                 if not cl or not json.loads(cl[-1][3:]).get("parity"):
