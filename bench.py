@@ -43,6 +43,9 @@ WORKLOADS = {
     "mixed": ("mixed", 64),
     "zeros": ("zeros", 64),
     "pointers_u64_128": ("pointers_u64", 128),
+    # 32-byte blocks (the block size of the paper's figure, reference MPC.PNG; north_star: "32/64/128 B")
+    "random_u32_32": ("random_u32", 32),
+    "mixed_32": ("mixed", 32),
 }
 
 
@@ -54,7 +57,7 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0, 
     gen = {"random_u32": traces.random_u32, "sine_f32": traces.sine_f32, "mixed": traces.mixed,
            "zeros": traces.zeros, "pointers_u64": traces.pointers_u64}[kind]
     host_cores = len(os.sched_getaffinity(0))      # cores this process may run on
-    cores = max(1, min(host_cores, 16))            # threads actually started (capped at 16)
+    cores = max(1, host_cores)                     # one thread per core: the node's own host cores, all of them
     cfg = configs.probe_config(L)
     make = {"VPC": lambda: O.VpcOracle(cfg), "BDI": lambda: O.BdiOracle(L), "FPC": lambda: O.FpcOracle(L), "BPC": lambda: O.BpcOracle(L)}[algo]
     # calibrate on a short run, then size the sample for ~`seconds` of wall time
@@ -75,7 +78,7 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0, 
         t.join()
     dt = time.perf_counter() - t0
     return {"value": cores * per_thread / dt, "unit": "blocks/s", "cores": cores, "host_cores": host_cores,
-            "thread_cap": 16, "kind": "port",
+            "kind": "port",
             "sample": f"{per_thread} {workload} {L} B blocks per thread x {cores} threads "
                       f"(oracle/mpc_oracle.c, {'probe config' if algo == 'VPC' else algo}), {dt:.1f} s",
             "single_core_blocks_per_s": rate1}
@@ -134,8 +137,19 @@ def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, byte
 
 
 SUB_WORKLOADS = [("sine_f32", "VPC"), ("mixed", "VPC"), ("zeros", "VPC"), ("pointers_u64_128", "VPC"),
-                 ("random_u32", "BDI"), ("sine_f32", "BDI"), ("mixed", "BDI"), ("pointers_u64_128", "BDI"),
+                 ("random_u32_32", "VPC"), ("mixed_32", "VPC"),
+                 ("random_u32", "BDI"), ("sine_f32", "BDI"), ("mixed", "BDI"), ("pointers_u64_128", "BDI"), ("random_u32_32", "BDI"),
                  ("random_u32", "FPC"), ("random_u32", "BPC")]
+
+
+def traffic_record(tj, algo, workload, L, n):
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes) recorded in profiles/traffic.json, with the file they were condensed from: a number
+    of ANOTHER run of the same workload and build generation, not of this one."""
+    e = tj.get(f"{algo}/{workload}/{L}/{n}")
+    if not e:
+        return None, None
+    return e.get("bytes"), e.get("source")
 
 
 def main():
@@ -149,8 +163,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true",
                     help="skip the sub-records of the other BASELINE workloads (sine, mixed, zeros, 128 B pointers; VPC and BDI)")
-    ap.add_argument("--config4-lines", type=int, default=512 << 20,
-                    help="N > 1: blocks per GPU of the BASELINE config 4 sub-record (mixed int/fp, 4 Gi blocks over 8 GPUs)")
+    ap.add_argument("--config4-lines", type=int, default=None,
+                    help="N > 1: blocks per GPU of the BASELINE config 4 sub-record (mixed int/fp, 4 Gi blocks over 8 GPUs; "
+                         "default 512 Mi, or --lines in a single-GPU rehearsal)")
     ap.add_argument("--rehearse-single-gpu", action="store_true",
                     help="development: run the N>1 code path with every rank on cuda:0 and the gloo backend "
                          "(a 1-GPU box cannot host an RCCL group); never used for reported numbers")
@@ -269,7 +284,7 @@ def main():
     # stays on the N = 1 workload so that the scaling curve is comparable).
     config4 = None
     if world > 1:
-        n4 = min(args.config4_lines, args.lines) if args.rehearse_single_gpu else args.config4_lines
+        n4 = args.config4_lines if args.config4_lines else (min(512 << 20, args.lines) if args.rehearse_single_gpu else 512 << 20)
         del buf
         torch.cuda.empty_cache()
         buf4 = torch.empty(n4 * 64, dtype=torch.uint8, device=dev)
@@ -307,14 +322,14 @@ def main():
         ev4.close()
 
     if rank == 0:
-        traffic = args.traffic_bytes
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tj = json.load(f)
+        except OSError:
+            tj = {}
+        traffic, traffic_source = args.traffic_bytes, "--traffic-bytes"
         if traffic is None:
-            # HBM bytes per launch measured in a separate rocprofv3 --pmc pass of this exact workload
-            try:
-                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                    traffic = json.load(f).get(f"{args.algo}/{args.workload}/{L}/{n}", {}).get("bytes")
-            except OSError:
-                traffic = None
+            traffic, traffic_source = traffic_record(tj, args.algo, args.workload, L, n)
         achieved = n * L / avg_kern_s / 1e9     # algorithmic bytes: L read per block
         out = {
             "metric": "64B blocks/s (whole node) + achieved HBM GB/s fraction; ratio bit-exact vs CPU",
@@ -334,7 +349,7 @@ def main():
                        "algorithm": args.algo, "line_size": L, "blocks_per_gpu": n,
                        "sharding": f"contiguous x{world}", "compression_ratio": ratio},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name,
                          "kernel_ms_avg": avg_kern_s * 1e3, "kernel_ms_min": min(kern_ms),
                          "algorithmic_bytes_per_launch": n * L,
@@ -345,15 +360,14 @@ def main():
         else:
             out["cpu_baseline"] = None
         if workloads is not None:
-            # HBM bytes per launch from the separate rocprofv3 --pmc passes recorded in profiles/traffic.json
-            try:
-                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                    tj = json.load(f)
-            except OSError:
-                tj = {}
             for w in workloads:
-                w["roofline"]["traffic"] = tj.get(f"{w['algorithm']}/{w['workload']}/{w['line_size']}/{w['blocks']}", {}).get("bytes")
+                w["roofline"]["traffic"], w["roofline"]["traffic_source"] = traffic_record(
+                    tj, w["algorithm"], w["workload"], w["line_size"], w["blocks"])
             out["workloads"] = workloads
+        if world > 1:
+            # what the collective of the timed steps ran on, at the top level of the line
+            out["rccl_ranks"] = dist.get_world_size()
+            out["collective_backend"] = dist.get_backend() + (" (single-GPU rehearsal)" if args.rehearse_single_gpu else " (RCCL)")
         if config4 is not None:
             out["config4"] = config4
         print(json.dumps(out), flush=True)

@@ -273,8 +273,9 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     const Module &m = cfg.modules[(size_t)(cfg.start + q)];
     MpcFastModule &f = P.fm[q];
     const std::string tag = "module " + std::to_string(cfg.start + q) + ": ";
-    // one scan order for the whole configuration: plane-major, or byte-major (a table of 8 entries or fewer is both:
-    // it is taken as whatever the first module is)
+    // one scan order for the whole configuration: plane-major, or byte-major.  Entry i of a plane-major table is (row 0,
+    // column i), of a byte-major one (row i, column 0), so only a table of at most ONE entry is both; the plane-major test
+    // runs first, and every module must have module 0's order and TableSize.
     const Module &m0 = cfg.modules[(size_t)cfg.start];
     const bool bm0 = !is_plane_major_scan(m0, L) && is_byte_major_scan(m0, L);
     if (!(bm0 ? is_byte_major_scan(m, L) : is_plane_major_scan(m, L))) {

@@ -1,9 +1,11 @@
 // Compressor.h -- evaluator interface, source-compatible with the reference's
-// comp::Compressor (reference src/compressor/Compressor.h:18-33).  ADDITIVE:
-// CompressBatch()/CompressFile(), which the driver uses when the loader can hand
-// out many lines at once; the per-line CompressLine() keeps its signature and
-// meaning (it evaluates one line on the device and returns its size in bits), unless
-// the driver opts into SetLineBuffering().
+// comp::Compressor (reference src/compressor/Compressor.h:18-33): a class that overrides only
+// CompressLine() (and GetResult()), like the reference's CPACK / SC2 / ... compressors, compiles
+// and runs against this header unchanged.  ADDITIVE and DEFAULTED: CompressBatch() / CompressFile() /
+// GetLineSize(), which the driver uses when the loader can hand out many lines at once -- the
+// defaults fall back to CompressLine() per line; the GPU evaluators (VPC, BDI, FPC, BPC) override
+// them.  The per-line CompressLine() keeps its signature and meaning (it evaluates one line and
+// returns its size in bits), unless the driver opts into SetLineBuffering().
 #ifndef MPC_HOST_COMPRESSOR_H
 #define MPC_HOST_COMPRESSOR_H
 
@@ -31,13 +33,23 @@ public:
   // Refreshes m_Stat from the device-side statistics and returns it (borrowed).
   virtual CompResult *GetResult() { return m_Stat; }
 
-  // ADDITIVE: n consecutive lines of GetLineSize() bytes; statistics accumulate.
-  virtual void CompressBatch(const uint8_t *lines, unsigned long long n) = 0;
+  // ADDITIVE: n consecutive lines of GetLineSize() bytes; statistics accumulate.  Default: CompressLine() per line.
+  virtual void CompressBatch(const uint8_t *lines, unsigned long long n)
+  {
+    const unsigned L = GetLineSize();
+    std::vector<uint8_t> line(L);
+    for (unsigned long long i = 0; i < n; i++) {
+      line.assign(lines + i * L, lines + (i + 1) * L);
+      CompressLine(line);
+    }
+  }
   // ADDITIVE: stream a whole trace file through the evaluator: a C-order uint8 [N, L] .npy
   // file (all rows but the last, as the reference driver does) or a GPGPU-Sim .log file (its
-  // GLOBAL_ACC_R / GLOBAL_ACC_W requests); returns the number of lines evaluated.
-  virtual unsigned long long CompressFile(const std::string &tracePath) = 0;
-  virtual unsigned GetLineSize() = 0;
+  // GLOBAL_ACC_R / GLOBAL_ACC_W requests); returns the number of lines evaluated.  Default
+  // (Compressor.cpp): the reference driver's loop, GetCacheline() -> CompressLine() per line.
+  virtual unsigned long long CompressFile(const std::string &tracePath);
+  // ADDITIVE: bytes per line.  Default: the result object's LineSize (CompResult.h).
+  virtual unsigned GetLineSize() { return m_Stat->LineSize; }
 
   // ADDITIVE: buffered per-line mode, for drivers that keep the reference's loop (GetCacheline ->
   // CompressLine per line, main.cpp:225-243 -- which never looks at CompressLine()'s return value).

@@ -19,10 +19,10 @@
 #include "LoaderAPSim.h"
 #include "LoaderGPGPU.h"
 #include "LoaderNPY.h"
-
-#define REQ_SIZE 32   // line size asked of the APSim loader (reference main.cpp:23)
 #include "VPC.h"
 #include "utils.h"
+
+#define REQ_SIZE 32   // line size asked of the APSim loader (reference main.cpp:23)
 
 static comp::CompResult *compressLines(comp::Compressor *compressor, trace::Loader *loader, bool perLine);
 
@@ -78,7 +78,15 @@ int main(int argc, char **argv)
     const std::string arg = argv[i];
     if (arg == "-h" || arg == "--help") { a.help = true; continue; }
     if (arg == "--per-line") { a.per_line = true; continue; }
-    if (arg == "--line-buffer" && i + 1 < argc) { a.per_line = true; a.line_buffer = strtoull(argv[++i], nullptr, 10); continue; }
+    if (arg == "--line-buffer") {
+      if (i + 1 >= argc) {
+        std::cout << "Option 'line-buffer' is missing an argument" << std::endl;
+        exit(1);
+      }
+      a.per_line = true;
+      a.line_buffer = strtoull(argv[++i], nullptr, 10);
+      continue;
+    }
     if (take_value(argc, argv, i, arg, "-a", "algorithm", a.algorithm, a.has_algorithm)) continue;
     if (take_value(argc, argv, i, arg, "-i", "input", a.input, a.has_input)) continue;
     if (take_value(argc, argv, i, arg, "-c", "config", a.config, a.has_config)) continue;
@@ -176,10 +184,10 @@ static comp::CompResult *compressLines(comp::Compressor *compressor, trace::Load
     compressor->CompressFile(path);
     return compressor->GetResult();
   }
-  const unsigned L = loader->GetCachelineSize();
-  const unsigned long long cap = (64ull << 20) / L;
-  std::vector<uint8_t> buf((size_t)(cap * L));
   if (!perLine && loader->SupportsBatch()) {
+    const unsigned L = loader->GetCachelineSize();
+    const unsigned long long cap = (64ull << 20) / L;
+    std::vector<uint8_t> buf((size_t)(cap * L));
     for (;;) {
       unsigned long long n = loader->GetBatch(buf.data(), cap);
       if (n == 0) break;
@@ -202,6 +210,7 @@ static comp::CompResult *compressLines(comp::Compressor *compressor, trace::Load
       }
       compressor->CompressLine(memReq->data);
     }
+    delete memReq;      // (the reference leaks its request object)
   }
   return compressor->GetResult();
 }

@@ -40,3 +40,85 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# ---- a clean box after the session ---------------------------------------------------------------------------------
+# Several tests start child processes (torch.distributed.run, multiprocessing spawn workers, the command line
+# binary, fresh interpreters for the grid-capped runs).  None of them may outlive the session, and nothing may be left
+# in /dev/shm (shared-memory segments live in RAM): the session ends by checking both, stopping what it finds (exact
+# process ids only) and failing if a worker of ours was still alive.
+def _descendants(root_pid):
+    kids = {}
+    for name in os.listdir("/proc"):
+        if not name.isdigit():
+            continue
+        try:
+            with open(f"/proc/{name}/stat") as f:
+                st = f.read()
+            rest = st[st.rindex(")") + 2:].split()
+            kids.setdefault(int(rest[1]), []).append((int(name), st[st.index("(") + 1:st.rindex(")")], rest[0]))
+        except (OSError, ValueError):
+            continue
+    out, todo = [], [root_pid]
+    while todo:
+        for pid, comm, state in kids.get(todo.pop(), []):
+            out.append((pid, comm, state))
+            todo.append(pid)
+    return out
+
+
+def _shm_names():
+    try:
+        return set(os.listdir("/dev/shm"))
+    except OSError:
+        return set()
+
+
+def pytest_sessionstart(session):
+    session.config._mpc_shm_before = _shm_names()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import signal
+    import time
+    me = os.getpid()
+    # helper daemons of multiprocessing / torch end with this process; anything else is a worker that leaked
+    benign = ("resource_tracker", "torch_shm_manag")
+    left = [(pid, comm, state) for pid, comm, state in _descendants(me) if state != "Z"]
+    workers = []
+    for pid, comm, state in left:
+        try:
+            with open(f"/proc/{pid}/cmdline", "rb") as f:
+                cmd = f.read().replace(b"\0", b" ").decode(errors="replace")
+        except OSError:
+            continue
+        if any(b in comm or b in cmd for b in benign):
+            continue
+        workers.append((pid, comm, cmd[:200]))
+    for pid, _, _ in workers:
+        try:
+            os.kill(pid, signal.SIGTERM)
+        except OSError:
+            pass
+    if workers:
+        time.sleep(1.0)
+        for pid, _, _ in workers:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
+                pass
+    new_shm = sorted(_shm_names() - getattr(session.config, "_mpc_shm_before", set()))
+    for name in new_shm:
+        try:
+            os.unlink(os.path.join("/dev/shm", name))
+        except OSError:
+            pass
+    if workers or new_shm:
+        tr = session.config.pluginmanager.get_plugin("terminalreporter")
+        msg = f"session left behind: processes {workers} /dev/shm {new_shm}"
+        if tr:
+            tr.write_line(msg, red=True)
+        else:
+            print(msg)
+    if workers:
+        session.exitstatus = 1

@@ -179,3 +179,26 @@ def test_datatype_model_configs_are_fast_path(mpc, configs, oracle):
         d = mpc.describe_config(configs.mpc_config(L))
         assert d["rc"] == 0 and d["path"] == "fast" and d["M"] == 7, (L, d)
         oracle.VpcOracle(configs.mpc_config(L))
+
+
+def test_short_scan_tables_pin_the_scan_order(mpc, configs):
+    """Entry i of a plane-major scan table is (row 0, column i) for i < L, of a byte-major one (row i % 8, column
+    i / 8): only a table of at most one entry is both (and is taken as plane-major, the test that runs first).
+    Truncated byte-major tables of 2 .. 8 entries -- a single column -- must be classified byte-major, the
+    plane-major ones of the same sizes plane-major; a table that is neither goes to the generic kernel."""
+    L = 64
+    for ts in range(0, 10):
+        bm = {"TableSize": ts, "Rows": [i % 8 for i in range(ts)], "Cols": [i // 8 for i in range(ts)]}
+        pm = {"TableSize": ts, "Rows": [i // L for i in range(ts)], "Cols": [i % L for i in range(ts)]}
+        for want, sc in (("byte-major" if ts >= 2 else "plane-major", bm), ("plane-major", pm)):
+            mods = [{"name": "AllZero"}, configs.one_base(L, 0, True, sc), configs.consecutive_base(L, 0, False, sc)]
+            d = mpc.describe_config(configs.make_config(L, mods))
+            assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "run-time loop", (ts, d)
+            assert d["scan_order"] == want, (ts, want, d["scan_order"])
+    # the two orders in one configuration: no fast form
+    ts = 5
+    bm = {"TableSize": ts, "Rows": [i % 8 for i in range(ts)], "Cols": [i // 8 for i in range(ts)]}
+    pm = {"TableSize": ts, "Rows": [0] * ts, "Cols": list(range(ts))}
+    d = mpc.describe_config(configs.make_config(L, [{"name": "AllZero"}, configs.one_base(L, 0, True, bm), configs.one_base(L, 0, False, pm)]))
+    assert d["path"] == "generic"
+    assert mpc.describe_config(configs.probe_config(L))["scan_order"] == "plane-major"

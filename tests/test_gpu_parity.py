@@ -244,7 +244,7 @@ def test_vpc_fast_path_nonzero_root_and_truncated_scan(mpc, oracle, configs, tra
     # byte-major scan order (scanned bit i = plane i % 8 of byte i / 8: rows are byte pairs), full and truncated, any root
     def bytemajor(ts=8 * L):
         return {"TableSize": ts, "Rows": [i % 8 for i in range(ts)], "Cols": [i // 8 for i in range(ts)]}
-    for ts, root in ((8 * L, 0), (8 * L, 6), (8 * L - 20, 0), (5 * L + 3, 2), (24, 0)):
+    for ts, root in ((8 * L, 0), (8 * L, 6), (8 * L - 20, 0), (5 * L + 3, 2), (24, 0), (8, 0), (5, 3), (2, 0)):      # (down to a single column)
         mods = [az, aws, configs.one_base(L, root, True, bytemajor(ts)), configs.consecutive_base(L, 0, False, bytemajor(ts)),
                 configs.diff_base(L, prev4, diff, root, True, bytemajor(ts)), configs.weight_base(L, prev4, w2, 0, False, bytemajor(ts))]
         _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:3000], expect_path=mpc.MPC_PATH_VPC_FAST)
@@ -748,7 +748,9 @@ def test_bench_two_rank_rehearsal_child_process():
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--rehearse-single-gpu", "--lines", "1048576", "--steps", "2", "--warmup", "1"]
+           "--gpus", "2", "--rehearse-single-gpu", "--lines", "1048576", "--steps", "2", "--warmup", "1",
+           # a config-4 shard LARGER than the primary buffer: the primary buffer is released and the shard allocated anew
+           "--config4-lines", "3145728"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
@@ -758,8 +760,12 @@ def test_bench_two_rank_rehearsal_child_process():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
     assert d["config"]["blocks_per_gpu"] == 1048576 and d["config"]["sharding"] == "contiguous x2"
     assert d["value"] > 0 and d["roofline"]["kernel"] == "vpc_lane_kernel<16>"
+    # the collective's group size and backend at the top level of the line (a driver-run record can be checked for
+    # "the collective saw N ranks" without parsing the sub-record)
+    assert d["rccl_ranks"] == 2 and d["collective_backend"].startswith("gloo")
     c4 = d["config4"]
     assert c4["rccl_ranks"] == 2 and c4["sharding"] == "contiguous x2"
+    assert c4["workload"].startswith(str(2 * 3145728) + " mixed")
     assert 0.0 <= c4["all_reduce_share_of_pass"] < 1.0 and c4["blocks_per_s"] > 0
     # random u32 blocks stay uncompressed at 515 bits, mixed blocks compress
     assert abs(d["config"]["compression_ratio"] - 512.0 / 515.0) < 1e-6

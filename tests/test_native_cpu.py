@@ -219,3 +219,25 @@ def test_loader_apsim_txt_rejects_bad_files(loader_probe, traces, tmp_path):
                       ("badhex.txt", "row of the GPU traffic file")):
         r = subprocess.run([loader_probe, str(tmp_path / name), "line"], capture_output=True, text=True)
         assert r.returncode == 1 and msg in r.stdout, (name, r.stdout, r.stderr[-500:])
+
+
+def test_reference_style_subclass_compiles_against_compressor_h(traces, tmp_path):
+    """A compressor that overrides only CompressLine() -- the reference's two-method interface
+    (src/compressor/Compressor.h:18-33), like its CPACK / SC2 classes -- compiles against
+    cal_22-mpc_amd/host/Compressor.h unchanged, and the defaulted additive CompressBatch() / CompressFile() /
+    GetLineSize() give what the reference driver's per-line loop gives (.npy: all rows but the last; .log: the
+    GLOBAL_ACC_R / GLOBAL_ACC_W requests).  ASan / UBSan build, no device library."""
+    probe = _build(str(tmp_path), "subclass_probe",
+                   ["g++", "-std=c++17", *SAN, "-Wall", "-Werror", "-I", HOST, os.path.join(NATIVE, "subclass_probe.cpp"),
+                    os.path.join(HOST, "Compressor.cpp"), os.path.join(HOST, "CompResult.cpp"), os.path.join(HOST, "LoaderNPY.cpp"),
+                    os.path.join(HOST, "LoaderGPGPU.cpp"), os.path.join(HOST, "LoaderAPSim.cpp"), os.path.join(HOST, "utils.cpp")])
+    L = 64
+    lines = traces.structured(1234, L, seed=9)
+    npy = traces.save_npy(str(tmp_path / "t.npy"), lines)
+    types = np.random.default_rng(3).integers(0, 9, len(lines))
+    log = traces.write_gpgpusim_log(str(tmp_path / "t.log"), lines, types)
+    for path, kept in ((npy, lines[:-1]), (log, lines[(types == 0) | (types == 4)])):
+        r = subprocess.run([probe, path, str(L)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        want = f"{len(kept)} {len(kept) * L * 8} {int((kept != 0).sum()) * 8 + len(kept)}"
+        assert r.stdout.strip().split("\n") == [f"line {want}", f"batch {want}", f"file {want}"], r.stdout
