@@ -56,29 +56,42 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0, 
     kind = WORKLOADS[workload][0]
     gen = {"random_u32": traces.random_u32, "sine_f32": traces.sine_f32, "mixed": traces.mixed,
            "zeros": traces.zeros, "pointers_u64": traces.pointers_u64}[kind]
-    host_cores = len(os.sched_getaffinity(0))      # cores this process may run on
-    cores = max(1, host_cores)                     # one thread per core: the node's own host cores, all of them
+    host_cores = len(os.sched_getaffinity(0))      # cores this process may run on ...
+    quota = None                                   # ... and the CPU time its control group grants (cores' worth)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    cores = max(1, host_cores if quota is None else min(host_cores, int(quota + 0.5)))     # one thread per usable core
     cfg = configs.probe_config(L)
     make = {"VPC": lambda: O.VpcOracle(cfg), "BDI": lambda: O.BdiOracle(L), "FPC": lambda: O.FpcOracle(L), "BPC": lambda: O.BpcOracle(L)}[algo]
-    # calibrate on a short run, then size the sample for ~`seconds` of wall time
+
+    def run(per_thread):
+        data = gen(per_thread, L)
+        oracles = [make() for _ in range(cores)]
+        ths = [threading.Thread(target=oracles[i].compress, args=(data,)) for i in range(cores)]  # ctypes drops the GIL
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return time.perf_counter() - t0
+    # single-thread rate on a short run; then a pilot with every thread running (the threads may share fewer cores than
+    # they are), which sizes the sample for ~`seconds` of wall time
     cal_n = 4096
     cal = gen(cal_n, L)
     o = make()
     t0 = time.perf_counter()
     o.compress(cal, stats=True)
     rate1 = cal_n / (time.perf_counter() - t0)
-    per_thread = int(min(max(rate1 * seconds, 4096), 4 << 20))
-    data = gen(per_thread, L)
-    oracles = [make() for _ in range(cores)]
-    ths = [threading.Thread(target=oracles[i].compress, args=(data,)) for i in range(cores)]  # ctypes drops the GIL
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    dt = time.perf_counter() - t0
+    pilot_n = 2048
+    pilot_rate = cores * pilot_n / run(pilot_n)
+    per_thread = int(min(max(pilot_rate * seconds / cores, 2048), 4 << 20))
+    dt = run(per_thread)
     return {"value": cores * per_thread / dt, "unit": "blocks/s", "cores": cores, "host_cores": host_cores,
-            "kind": "port",
+            "cgroup_cpu_quota_cores": quota, "kind": "port",
             "sample": f"{per_thread} {workload} {L} B blocks per thread x {cores} threads "
                       f"(oracle/mpc_oracle.c, {'probe config' if algo == 'VPC' else algo}), {dt:.1f} s",
             "single_core_blocks_per_s": rate1}

@@ -76,6 +76,28 @@ def _shm_names():
 
 def pytest_sessionstart(session):
     session.config._mpc_shm_before = _shm_names()
+    # Orphans come home.  A helper whose parent exits first (the resource tracker of a torch.distributed.run agent, for
+    # one) is re-parented to process 1, which on the GPU boxes never reaps: it stays behind as a zombie after the
+    # session (seen in round 2: "the box could not be shown clean").  As a child subreaper this process inherits such
+    # orphans instead and reaps them at the end of the session.
+    try:
+        import ctypes
+        ctypes.CDLL(None, use_errno=True).prctl(36, 1, 0, 0, 0)      # PR_SET_CHILD_SUBREAPER
+    except Exception:
+        pass
+
+
+def _reap_children():
+    n = 0
+    while True:
+        try:
+            pid, _ = os.waitpid(-1, os.WNOHANG)
+        except ChildProcessError:
+            break
+        if pid == 0:
+            break
+        n += 1
+    return n
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -84,6 +106,7 @@ def pytest_sessionfinish(session, exitstatus):
     me = os.getpid()
     # helper daemons of multiprocessing / torch end with this process; anything else is a worker that leaked
     benign = ("resource_tracker", "torch_shm_manag")
+    _reap_children()
     left = [(pid, comm, state) for pid, comm, state in _descendants(me) if state != "Z"]
     workers = []
     for pid, comm, state in left:
@@ -107,6 +130,8 @@ def pytest_sessionfinish(session, exitstatus):
                 os.kill(pid, signal.SIGKILL)
             except OSError:
                 pass
+    time.sleep(0.2)
+    _reap_children()           # exited children and adopted orphans: no zombies stay behind
     new_shm = sorted(_shm_names() - getattr(session.config, "_mpc_shm_before", set()))
     for name in new_shm:
         try:

@@ -730,7 +730,7 @@ def test_two_rank_sharded_npy(mpc, oracle, configs, traces, tmp_path):
         assert (np.load(tmp_path / f"tot_{r}.npy") == o.stats_vector()).all()
 
 
-def test_bench_two_rank_rehearsal_child_process():
+def test_bench_two_rank_rehearsal_child_process(tmp_path):
     """bench.py's N > 1 path (contiguous shards, the all-reduce of the device accumulators, the
     max-over-ranks timing, the config 4 sub-record) run as a FRESH child process under
     torch.distributed.run -- two ranks on the one GPU of this box with the gloo backend (an RCCL group
@@ -747,7 +747,8 @@ def test_bench_two_rank_rehearsal_child_process():
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "--log-dir", str(tmp_path / "elastic"),      # (else /tmp/torchelastic_*)
+           os.path.join(root, "bench.py"),
            "--gpus", "2", "--rehearse-single-gpu", "--lines", "1048576", "--steps", "2", "--warmup", "1",
            # a config-4 shard LARGER than the primary buffer: the primary buffer is released and the shard allocated anew
            "--config4-lines", "3145728"]
