@@ -20,6 +20,7 @@ CLI = os.path.join(ROOT, "bin", "compressor")
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("MPC_EXTRA_FLAGS", "").split()      # development: extra -D switches for a variant build
 
 
 def _newer(target: str, sources) -> bool:

@@ -245,7 +245,10 @@ bool parallel_pread(int fd, void *dst, size_t bytes, u64 file_off)
 // Workgroups per CU of the grid-stride VPC and BDI kernels.  2-8 are resident; a grid of 32 per
 // CU lets CUs that finish early pick up more work (same-box A/B against 8 per CU: VPC random
 // -3.5 %, mixed -5 %, 128-byte lines -9 %, all-zero traces +3 %; BDI random -8 %, pointers -10 %).
-constexpr int kWgPerCu = 32;
+#ifndef MPC_WG_PER_CU
+#define MPC_WG_PER_CU 32
+#endif
+constexpr int kWgPerCu = MPC_WG_PER_CU;
 
 int grid_for(const mpc_handle *h, u64 work_items, int block, int per_cu)
 {

@@ -7,6 +7,7 @@
 //   bpc_kernel             BPC baseline (reference src/compressor/BPC.cpp)
 //   synth_kernel / read_probe_kernel   measurement helpers
 #include "mpc_kernel_common.h"
+#include "mpc_ring.h"
 
 // ---------------------------------------------------------------------------
 // generic VPC kernel: one lane per line, byte loops, any configuration.
@@ -495,15 +496,25 @@ __device__ __forceinline__ void bdi_line(const u32 (&w)[NW], bool active, bool r
   }
 }
 
-constexpr u32 kBdiQueue = 512;      // deferred lines per wave (LDS)
+constexpr u32 kBdiQueue = 384;      // deferred lines per wave (LDS)
 
+// Lines stream through a per-wave ring in LDS (mpc_ring.h: LDS-DMA, non-temporal, one line per lane on the way out):
+// ONE stage of 64 lines per wave, re-requested as soon as it has been read out, groups assigned grid-stride.  With so
+// little arithmetic behind a line (random data: every scan is screened out) the kernel sits on the floor of its access
+// pattern, and that floor is higher for the ring than for lane-per-line register loads: same box, ms per 16 GiB,
+// random 3.07 -> 2.84, sine 3.29 -> 3.12, mixed 3.27 -> 3.06, 128-byte pointers 2.82 -> 2.69.  (Two stages per wave
+// leave room for 4 instead of 7 workgroups per CU and measured slower on every trace; FPC and BPC, which already
+// transposed coalesced non-temporal loads through LDS, gain nothing from the ring and keep their form.)
 template <int NW>   // words per line
 __global__ void __launch_bounds__(256)
 bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ sizes_out,
            int8_t *__restrict__ sel_out, u64 *gstats)
 {
+  constexpr int NQ = NW / 4;
+  constexpr u32 SB = 64u * 16u * NQ;            // bytes of a stage
   __shared__ u64 s_counts[MPC_BDI_RAW_LEN];
   __shared__ u32 s_queue[4][kBdiQueue];
+  __shared__ __attribute__((aligned(1024))) uint4 s_ring[4 * 64 * NQ];
   if (threadIdx.x < MPC_BDI_RAW_LEN) s_counts[threadIdx.x] = 0;
   __syncthreads();
   // run-length accumulation per lane: (select, size) key, count
@@ -532,13 +543,13 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
     }
   };
   const u32 lane = threadIdx.x & 63u;
-  u32 *queue = s_queue[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+  const u32 wave = uni(threadIdx.x >> 6);
+  u32 *queue = s_queue[wave];
 
   u32 qn = 0;                                   // queued lines of this wave (wave-uniform)
   const bool can_defer = n_lines <= 0xffffffffull;      // queue entries are 32-bit line indices
-  const u64 stride = (u64)gridDim.x * blockDim.x;
   // the queued lines, 64 at a time, every scan they need
-  auto drain = [&]() {
+  auto drain = [&]() __attribute__((always_inline)) {
     while (qn > 0u) {
       const u32 take = qn < 64u ? qn : 64u;
       qn -= take;
@@ -557,12 +568,8 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
       if (active) account(line, best, select);
     }
   };
-  // wave-uniform loop over groups of 64 lines (every lane stays in the loop: qn must stay uniform)
-  for (u64 line0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); line0 < n_lines; line0 += stride) {
-    const u64 line = line0 + lane;
-    const bool active = line < n_lines;
-    u32 w[NW];
-    fetch(w, active ? line : n_lines - 1);
+  // one group of 64 lines held in w (every lane stays in: qn must stay uniform)
+  auto group = [&](const u32 (&w)[NW], u64 line, bool active) __attribute__((always_inline)) {
     u32 best;
     int select;
     bool deferred;
@@ -575,6 +582,41 @@ bdi_kernel(const uint4 *__restrict__ lines, u64 n_lines, uint16_t *__restrict__ 
     }
     if (active && !deferred) account(line, best, select);
     if (qn + 64u > kBdiQueue) drain();        // wave-uniform: room for the next group's deferrals
+  };
+
+  // ---- whole groups of 64 lines through the ring, grid-stride over the waves ----
+  const u32 ring_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) void *)s_ring + wave * SB;
+  u32 lane_off[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; j++) lane_off[j] = ring_src_off<NQ>(j, lane);
+  const u32 rd0 = (ring_lds + 16u * NQ * lane) | (16u * ring_swz<NQ>(lane));
+  const u64 full_groups = n_lines >> 6, gstride = (u64)gridDim.x * 4u;
+  u64 g = (u64)blockIdx.x * 4u + wave;
+  auto request = [&](u64 gg) { ring_request<NQ>(lane_off, lines + gg * (64u * NQ), ring_lds); };
+  if (g < full_groups) request(g);
+  while (g < full_groups) {
+    qn = uni(qn);
+    ring_wait_vm<0>();
+    u32 a[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) a[j] = rd0 ^ (16u * (u32)j);
+    uint4 v[NQ];
+    ring_read<NQ>(v, a);
+    if (uni(g + gstride < full_groups)) request(g + gstride);       // the stage is free again
+    __builtin_amdgcn_sched_barrier(0);
+    u32 w[NW];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { w[4 * i] = v[i].x; w[4 * i + 1] = v[i].y; w[4 * i + 2] = v[i].z; w[4 * i + 3] = v[i].w; }
+    group(w, g * 64u + lane, true);
+    g += gstride;
+  }
+  // ---- the launch's last, partial group: plain loads, by one wave ----
+  if ((n_lines & 63ull) != 0ull && blockIdx.x == 0 && wave == 0u) {
+    const u64 line = full_groups * 64u + lane;
+    const bool active = line < n_lines;
+    u32 w[NW];
+    fetch(w, active ? line : n_lines - 1);
+    group(w, line, active);
   }
   drain();
   if (run_cnt) {

@@ -28,6 +28,7 @@
 // sequence is unrolled; configurations whose sequence has no instantiation run the
 // same stages with a run-time loop over the modules.
 #include "mpc_kernel_common.h"
+#include "mpc_ring.h"
 
 #ifndef MPC_ABLATE
 #define MPC_ABLATE 0   // development-only timing ablations (tools/ablate.sh); results are WRONG when non-zero
@@ -907,101 +908,6 @@ __device__ __forceinline__ void lane_fetch(uint4 (&v)[NQ], const uint4 *__restri
 // VGPRs and spilled at 4 waves per SIMD; its lane-per-line loads stream at 6.2 TB/s where these reach 7.0-7.15 TB/s
 // (all-zero trace 2.9 -> 2.4 ms per 16 GiB); and with two stages (128 consecutive lines resident) a wave can take
 // the even and the odd lines of the block as its two groups at no cost in memory traffic (paired groups, below).
-#ifndef MPC_RING_NT
-#define MPC_RING_NT 1   /* non-temporal DMA loads */
-#endif
-
-template <int NQ>
-__device__ __forceinline__ u32 ring_swz(u32 line) { return (line >> (NQ == 2 ? 3 : (NQ == 4 ? 2 : 1))) & (u32)(NQ - 1); }
-
-// byte offset (from the group's first byte) of the 16-byte unit that lane `lane` of DMA instruction j fetches,
-// less what the request's base and the instruction's offset field add (1 KiB per instruction)
-template <int NQ>
-__device__ __forceinline__ u32 ring_src_off(int j, u32 lane)
-{
-  const u32 q = 64u * (u32)j + lane, line = q / NQ, pos = q % NQ;
-  return 16u * (line * NQ + (pos ^ ring_swz<NQ>(line))) - 1024u * (u32)j;
-}
-
-// LDS byte offset (inside a stage) of piece k of line `ll` (0..63)
-template <int NQ>
-__device__ __forceinline__ u32 ring_rd_off(u32 ll, int k) { return 16u * (ll * NQ + ((u32)k ^ ring_swz<NQ>(ll))); }
-
-#if MPC_RING_NT
-#define MPC_GLDS_AUX " nt"
-#else
-#define MPC_GLDS_AUX ""
-#endif
-// up to 4 KiB (NP pieces of 1 KiB) from global memory into LDS at lds_dst; M0 carries the LDS base and is put back
-// (the compiler reserves it and does not see it change inside the statement).  No "memory" clobber: nothing the
-// compiler knows about is written (the stage is only ever read by ring_read's statement, and volatile statements
-// keep their order); with one, every table read behind it would stop being a scalar load.
-template <int NP>
-__device__ __forceinline__ void ring_glds(const u32 *lane_off, const void *gbase, u32 lds_dst)
-{
-  u32 keep;
-  if constexpr (NP == 4)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %5" MPC_GLDS_AUX "\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024" MPC_GLDS_AUX "\n\t"
-                 "global_load_lds_dwordx4 %3, %5 offset:2048" MPC_GLDS_AUX "\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072" MPC_GLDS_AUX "\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_off[0]), "v"(lane_off[1]), "v"(lane_off[2]), "v"(lane_off[3]), "s"(gbase), "s"(lds_dst));
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %3" MPC_GLDS_AUX "\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024" MPC_GLDS_AUX "\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_off[0]), "v"(lane_off[1]), "s"(gbase), "s"(lds_dst));
-}
-
-// one group of 64 lines (NQ KiB) into the stage at lds_dst
-template <int NQ>
-__device__ __forceinline__ void ring_request(const u32 (&lane_off)[NQ], const uint4 *gbase_, u32 lds_dst_)
-{
-  // wave-uniform by construction; said so explicitly (the asm statements need scalar registers)
-  const u64 gb = reinterpret_cast<u64>(gbase_);
-  const u32 gb_hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(gb >> 32)), gb_lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)gb);
-  const uint4 *gbase = reinterpret_cast<const uint4 *>(((u64)gb_hi << 32) | (u64)gb_lo);      // (the builtin returns a signed int)
-  const u32 lds_dst = (u32)__builtin_amdgcn_readfirstlane((int)lds_dst_);
-  if constexpr (NQ == 8) {
-    ring_glds<4>(&lane_off[0], gbase, lds_dst);
-    ring_glds<4>(&lane_off[4], gbase + 256, lds_dst + 4096u);
-  } else {
-    ring_glds<NQ>(&lane_off[0], gbase, lds_dst);
-  }
-}
-
-// The streaming loop's state is wave-uniform by construction, but the compiler's divergence analysis gives up on values
-// that travel through the group code by reference (it then keeps them in vector registers and branches with EXEC masks:
-// +40 vector instructions per group, measured).  uni() says so explicitly: the value of the first active lane, in a scalar
-// register.
-__device__ __forceinline__ u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
-__device__ __forceinline__ bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
-
-// wait until at most N of the wave's vector-memory operations (the DMA instructions, in issue order) are outstanding
-template <int N>
-__device__ __forceinline__ void ring_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N)); }
-
-// the line at LDS addresses a[0..NQ-1] (one 16-byte piece each) into v; the reads and their wait are one statement
-template <int NQ>
-__device__ __forceinline__ void ring_read(uint4 (&v)[NQ], const u32 (&a)[NQ])
-{
-  typedef u32 v4 __attribute__((ext_vector_type(4)));
-  v4 r[NQ];
-  if constexpr (NQ == 2)
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r[0]), "=&v"(r[1]) : "v"(a[0]), "v"(a[1]));
-  else if constexpr (NQ == 4)
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
-  else
-    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
-                 "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
-#pragma unroll
-  for (int k = 0; k < NQ; k++) v[k] = make_uint4(r[k].x, r[k].y, r[k].z, r[k].w);
-}
-
 // ---- workgroup shape and LDS plan of the unrolled-sequence kernels ----------------------------------------------
 // One LARGE workgroup per CU: 16 waves (8 for 128-byte lines, whose group code needs two waves' registers per SIMD
 // lane) share ONE histogram, which leaves the LDS for the rings.  Four 256-thread workgroups per CU would hold four
@@ -1014,8 +920,14 @@ __device__ __forceinline__ void ring_read(uint4 (&v)[NQ], const u32 (&a)[NQ])
 #ifndef MPC_LANE_WAVES_128
 #define MPC_LANE_WAVES_128 8
 #endif
+// (32-byte lines: the group code needs under 96 registers, so 5 waves per SIMD would fit as two workgroups of 10 waves
+// per CU -- measured 12 % SLOWER on random data and 23 % on the mixed trace than one workgroup of 16)
+#ifndef MPC_LANE_WAVES_32
+#define MPC_LANE_WAVES_32 16
+#endif
+__host__ __device__ constexpr int lane_wpb_of(int L) { return L <= 32 ? MPC_LANE_WAVES_32 : (L <= 64 ? MPC_LANE_WAVES : MPC_LANE_WAVES_128); }
 template <int W, int NPT>
-__host__ __device__ constexpr int lane_wpb() { return NPT == 0 ? 4 : (W <= 16 ? MPC_LANE_WAVES : MPC_LANE_WAVES_128); }
+__host__ __device__ constexpr int lane_wpb() { return NPT == 0 ? 4 : lane_wpb_of(4 * W); }
 
 // LDS layout: [sums][histogram + spare slot + block counter][queues: wpb x cap][pad to 1 KiB][rings: wpb x stages x 64 L]
 struct LaneLds {
@@ -1051,7 +963,7 @@ static LaneLds lane_lds_plan(const MpcVpcParams *P, int wpb, bool wants_queue)
 // ring_cfg: ring stages per wave (bits 0..7) | queue entries per wave << 8 (lane_lds_plan; the run-time loop ignores it)
 template <int W, bool OUT, int... KINDS>
 __global__ void __launch_bounds__((64 * lane_wpb<W, sizeof...(KINDS)>()),
-                                  (W <= 16 ? (sizeof...(KINDS) > 0 ? MPC_LB_WAVES : MPC_LB_WAVES_RT) : MPC_LB_WAVES_128))
+                                  (W <= 16 ? (sizeof...(KINDS) > 0 ? (W == 8 && MPC_LANE_WAVES_32 == 10 ? 5 : MPC_LB_WAVES) : MPC_LB_WAVES_RT) : MPC_LB_WAVES_128))
 vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
                 uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats, u32 ring_cfg)
 {
@@ -1278,7 +1190,7 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
       /* `grid` counts 256-thread workgroups, 32 per CU when the trace is long: two large workgroups per CU */     \
       /* (four of 512 threads), one resident; never more than one block of lines per wave would fill */           \
       const u64 want = (n_lines / 64u + (u64)wpb - 1u) / (u64)wpb;                                                 \
-      const u64 cap = (u64)grid / (wpb == 16 ? 16u : 8u);                                                          \
+      const u64 cap = (u64)grid / (wpb == 16 ? 16u : 8u);      /* 16 waves: 2 per CU; 8 or 10 waves: 4 per CU */  \
       wgrid = (int)(want < cap ? want : cap);                                                                      \
       if (wgrid < 1) wgrid = 1;                                                                                    \
     }                                                                                                              \
@@ -1355,7 +1267,7 @@ static bool lane_has_line_size(int L)
 // 1 when the module sequence has an unrolled instantiation whose rings fit the LDS (else the run-time loop runs it)
 extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P)
 {
-  const int wpb = P->L <= 64 ? MPC_LANE_WAVES : MPC_LANE_WAVES_128;
+  const int wpb = lane_wpb_of(P->L);
   if (lane_lds_plan(P, wpb, P->L <= 64).stages == 0) return 0;
 #define X(...) if (lane_seq_matches<__VA_ARGS__>(P)) return 1;
   MPC_LANE_SEQUENCES(X)
@@ -1367,7 +1279,7 @@ extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P)
 extern "C" size_t mpc_vpc_lane_smem(const MpcVpcParams *P)
 {
   if (!mpc_vpc_lane_unrolled(P)) return lane_stats_smem(P->M + 1, P->hist_bins);
-  const int wpb = P->L <= 64 ? MPC_LANE_WAVES : MPC_LANE_WAVES_128;
+  const int wpb = lane_wpb_of(P->L);
   return lane_lds_plan(P, wpb, P->L <= 64).bytes;
 }
 #endif
@@ -1399,7 +1311,7 @@ extern "C" hipError_t MPC_LAUNCH_NAME(const void *d_lines, u64 n_lines, const Mp
   if (!lane_has_line_size(P->L)) return hipErrorInvalidValue;
   const u64 max_lines = 1ull << 30;     // 32-bit line indices inside the kernel
   // a sequence whose rings do not fit the LDS beside its histogram runs the run-time module loop
-  const int wpb = P->L <= 64 ? MPC_LANE_WAVES : MPC_LANE_WAVES_128;
+  const int wpb = lane_wpb_of(P->L);
   const bool rings_fit = lane_lds_plan(P, wpb, P->L <= 64).stages != 0;
   for (u64 done = 0; done < n_lines; done += max_lines) {
     const u64 take = (n_lines - done) < max_lines ? (n_lines - done) : max_lines;
