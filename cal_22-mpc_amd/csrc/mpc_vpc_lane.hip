@@ -243,7 +243,10 @@ struct LaneBest {
 // it with strided register loads); the wave still probes with plain groups every kPairProbe blocks and stays with
 // them unless the sign is back, because the read-out of a paired group has 2-way LDS bank conflicts and the next
 // block can only be requested after both groups have been read.
-constexpr u32 kPairProbe = 64;
+#ifndef MPC_PAIR_PROBE
+#define MPC_PAIR_PROBE 64
+#endif
+constexpr u32 kPairProbe = MPC_PAIR_PROBE;
 
 // LDS bytes of the statistics: as vpc_stats_smem plus the spare histogram slot deferred lines are parked in
 __host__ __device__ static inline size_t lane_stats_smem(int K, int bins)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], int(sys.argv[2])
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 KERNELS = ("vpc_lane_kernel", "vpc_generic_kernel", "bdi_kernel", "fpc_kernel", "bpc_kernel")
-LINES = {64: 256 << 20, 128: 256 << 20}
+LINES = {32: 512 << 20, 64: 256 << 20, 128: 128 << 20}      # 16 GiB resident per workload (tools/profile_round.sh)
 
 
 def counters(path):
@@ -32,10 +32,11 @@ def counters(path):
 
 tj_path = os.path.join(ROOT, "profiles", "traffic.json")
 tj = json.load(open(tj_path))
+tj = {k: v for k, v in tj.items() if v.get("round") == rnd}      # entries of earlier rounds belong to other kernels
 for tr in sorted(glob.glob(os.path.join(src, "*_trace"))):
     base = os.path.basename(tr)[: -len("_trace")]          # ALGO_workload
     algo, wl = base.split("_", 1)
-    L = 128 if wl.endswith("_128") else 64
+    L = 128 if wl.endswith("_128") else (32 if wl.endswith("_32") else 64)
     n = LINES[L]
     dst = os.path.join(ROOT, "profiles", f"r{rnd:02d}_{tag}_kernel_stats_{base}.csv")
     shutil.copy(os.path.join(tr, "run_kernel_stats.csv"), dst)
@@ -61,6 +62,8 @@ for tr in sorted(glob.glob(os.path.join(src, "*_trace"))):
                 note = "KiB"
             elif name.startswith("SQ_"):
                 note = f"{val / (n / 64):.2f} per group of 64 lines"
+            elif name == "GRBM_GUI_ACTIVE":
+                note = "sum over the 8 XCDs: effective clock = value / 8 / kernel time"
             rows.append((f"{tag}_{kind}", kname, name, f"{val:.3f}", cnt, note))
     with open(os.path.join(ROOT, "profiles", f"r{rnd:02d}_{tag}_pmc_{base}.csv"), "w", newline="") as f:
         csv.writer(f).writerows(rows)
