@@ -128,25 +128,30 @@ struct WgStats {
   u64 *sums;   // [2 * K]    (LDS): sum_r, sum_r2
 };
 
-__device__ __forceinline__ void stats_init(const WgStats &s, int K, int bins)
+__device__ __forceinline__ void stats_init(const WgStats &s, int K, int bins, int tid, int nthreads)
 {
-  for (int i = threadIdx.x; i < K * bins; i += blockDim.x) s.hist[i] = 0;
-  for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) s.sums[i] = 0;
+  for (int i = tid; i < K * bins; i += nthreads) s.hist[i] = 0;
+  for (int i = tid; i < 2 * K; i += nthreads) s.sums[i] = 0;
   __syncthreads();
 }
+__device__ __forceinline__ void stats_init(const WgStats &s, int K, int bins) { stats_init(s, K, bins, threadIdx.x, blockDim.x); }
 
-__device__ __forceinline__ void stats_flush(const WgStats &s, int K, int bins, u64 *g)
+// tid / nthreads: the caller's thread index and workgroup size.  (A kernel that passes them as lane + 64 * wave and a
+// constant need not keep threadIdx.x and the dispatch packet's pointer alive from its first instruction to its last:
+// the lane kernel spilled exactly those.)
+__device__ __forceinline__ void stats_flush(const WgStats &s, int K, int bins, u64 *g, int tid, int nthreads)
 {
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) {
+  for (int i = tid; i < 2 * K; i += nthreads) {
     u64 v = s.sums[i];
     if (v) atomicAdd(&g[i], v);
   }
-  for (int i = threadIdx.x; i < K * bins; i += blockDim.x) {
+  for (int i = tid; i < K * bins; i += nthreads) {
     u32 v = s.hist[i];
     if (v) atomicAdd(&g[2 * K + i], (u64)v);
   }
 }
+__device__ __forceinline__ void stats_flush(const WgStats &s, int K, int bins, u64 *g) { stats_flush(s, K, bins, g, threadIdx.x, blockDim.x); }
 
 
 // LDS bytes of the per-workgroup statistics (sums then histogram)

@@ -979,7 +979,7 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
   E.st.sums = reinterpret_cast<u64 *>(smem);
   E.st.hist = reinterpret_cast<u32 *>(smem + 16 * ((2 * E.K * 8 + 15) / 16));
   if (threadIdx.x == 0) E.st.hist[E.K * E.bins + 1] = 0;     // the workgroup's block counter
-  stats_init(E.st, E.K, E.bins);   // ends with __syncthreads()
+  stats_init(E.st, E.K, E.bins, threadIdx.x, 64 * (int)WPB);   // ends with __syncthreads()
   E.defer_cap = ring_cfg >> 8;
   E.defer_q = reinterpret_cast<u32 *>(smem + lane_stats_smem(E.K, E.bins)) + (threadIdx.x >> 6) * E.defer_cap;
   E.enc_zero = (u32)P.enc_bits[1];
@@ -1120,33 +1120,40 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
         alt = false;
         cb = nb;
       }
-      // the lines behind the launch's last whole block (fewer than 128): plain loads, by one wave of the launch
-      if (!tail_done && cb == kNone && blockIdx.x == gridDim.x - 1u && wave == 0u && qn <= defer_high) {
-        for (u32 l0 = n_blocks * 128u; l0 < n_lines; l0 += 64u) {
-          lane_fetch<NQ>(va, lines, l0 + E.lane, n_lines);
-          lane_step<W, OUT, false, false, KINDS...>(va, l0, E.lane, 0u, true, P, E, rs, qn, alt);
+      // ---- drain: the queued lines, 64 at a time from the top of the queue; and, by one wave of the launch once its
+      // blocks are done, the lines behind the launch's last whole block (fewer than 128).  Both are groups of lines
+      // addressed per lane and fetched with plain loads: one copy of the group code serves them.
+      const bool tail_mine = !tail_done && cb == kNone && blockIdx.x == gridDim.x - 1u && wave == 0u;
+      u32 tail_l0 = n_blocks * 128u;
+      for (;;) {
+        u32 dline;
+        bool dvalid;
+        if (qn > 0u) {
+          const u32 take = qn < 64u ? qn : 64u;
+          qn -= take;
+          if (MPC_TESTING && E.lane == 0) {
+            route_add(routes, MPC_RT_VPC_DRAINS, 1u);
+            route_add(routes, MPC_RT_VPC_DEFERRED, take);
+          }
+          dvalid = E.lane < take;
+          dline = dvalid ? E.defer_q[qn + E.lane] : 0u;
+        } else if (tail_mine && tail_l0 < n_lines) {
+          dline = tail_l0 + E.lane;
+          dvalid = dline < n_lines;
+          tail_l0 += 64u;
           if (MPC_TESTING && E.lane == 0) route_add(routes, MPC_RT_VPC_TAIL_GROUPS, 1u);
+        } else {
+          break;
         }
-        tail_done = true;
-      }
-      // ---- drain: the queued lines, 64 at a time from the top of the queue ----
-      while (qn > 0u) {
-        const u32 take = qn < 64u ? qn : 64u;
-        qn -= take;
-        if (MPC_TESTING && E.lane == 0) {
-          route_add(routes, MPC_RT_VPC_DRAINS, 1u);
-          route_add(routes, MPC_RT_VPC_DEFERRED, take);
-        }
-        const bool dvalid = E.lane < take;
-        const u32 dline = dvalid ? E.defer_q[qn + E.lane] : 0u;
         lane_fetch<NQ>(va, lines, dline, n_lines);
         lane_step<W, OUT, false, true, KINDS...>(va, 0u, 0u, dline, dvalid, P, E, rs, qn, alt);
       }
+      if (tail_mine) tail_done = true;
       if (cb == kNone && (tail_done || blockIdx.x != gridDim.x - 1u || wave != 0u)) break;
     }
   }
   lane_run_flush(rs, E.st, E.K, E.bins);
-  stats_flush(E.st, E.K, E.bins, gstats);
+  stats_flush(E.st, E.K, E.bins, gstats, (int)(E.lane + 64u * wave), 64 * (int)WPB);
 }
 
 #define OB MPC_FK_ONEBASE

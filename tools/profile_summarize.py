@@ -32,7 +32,7 @@ def counters(path):
 
 tj_path = os.path.join(ROOT, "profiles", "traffic.json")
 tj = json.load(open(tj_path))
-tj = {k: v for k, v in tj.items() if v.get("round") == rnd}      # entries of earlier rounds belong to other kernels
+tj = {k: v for k, v in tj.items() if isinstance(v, dict) and v.get("round") == rnd}      # entries of earlier rounds belong to other kernels
 for tr in sorted(glob.glob(os.path.join(src, "*_trace"))):
     base = os.path.basename(tr)[: -len("_trace")]          # ALGO_workload
     algo, wl = base.split("_", 1)
