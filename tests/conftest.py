@@ -100,10 +100,24 @@ def _reap_children():
     return n
 
 
+def _stop_resource_tracker():
+    """multiprocessing's resource tracker is a helper child of THIS process (started by the first spawn); it only exits
+    when this process does and would then be an orphan of process 1 for a while -- what the round-2 record saw after
+    the GPU test step.  Stop it (close its pipe, wait for it) while we are still its parent."""
+    try:
+        from multiprocessing import resource_tracker
+        rt = getattr(resource_tracker, "_resource_tracker", None)
+        if rt is not None and getattr(rt, "_pid", None) is not None and hasattr(rt, "_stop"):
+            rt._stop()
+    except Exception:
+        pass
+
+
 def pytest_sessionfinish(session, exitstatus):
     import signal
     import time
     me = os.getpid()
+    _stop_resource_tracker()
     # helper daemons of multiprocessing / torch end with this process; anything else is a worker that leaked
     benign = ("resource_tracker", "torch_shm_manag")
     _reap_children()
