@@ -141,6 +141,7 @@ def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, byte
         ms.append(a.elapsed_time(b))
     v = ev.stats_vector()
     assert int(v[0]) == n * steps, (workload, algo, int(v[0]), n * steps)
+    check_known_ratio(algo, workload, L, n, float(v[1]) / float(v[2]))
     avg = sum(ms) / len(ms)
     achieved = n * L / (avg / 1e3) / 1e9
     rec = {"workload": workload, "algorithm": algo, "line_size": L, "blocks": n, "kernel": kernel_label(mpc, ev, algo, L),
@@ -156,6 +157,29 @@ SUB_WORKLOADS = [("sine_f32", "VPC"), ("mixed", "VPC"), ("zeros", "VPC"), ("poin
                  ("random_u32_32", "VPC"), ("mixed_32", "VPC"),
                  ("random_u32", "BDI"), ("sine_f32", "BDI"), ("mixed", "BDI"), ("pointers_u64_128", "BDI"), ("random_u32_32", "BDI"),
                  ("random_u32", "FPC"), ("random_u32", "BPC")]
+
+
+# Known answers of the reference for the synthetic traces under the probe configuration (SURVEY.md 8c / BASELINE.md 2): the
+# compression ratio is a property of the trace's period, not of its length, so it is checked at the full 16 GiB too.
+KNOWN_RATIO = {
+    ("VPC", "zeros", 64): 512.0 / 3.0,                        # every line 3 bits
+    ("VPC", "random_u32", 64): None,                          # 512 / 515 but for a handful of lines that compress: bounded below
+    ("VPC", "sine_f32", 64): 4096.0 * 512.0 / 2105344.0,      # one 4096-line period: 3456 lines at 515 b, 640 in cluster 5
+    ("BDI", "pointers_u64_128", 128): 1024.0 / 564.0,         # every line B8D4
+}
+
+
+def check_known_ratio(algo, workload, L, n, ratio):
+    key = (algo, workload, L)
+    if key not in KNOWN_RATIO:
+        return
+    want = KNOWN_RATIO[key]
+    if want is None:
+        assert 512.0 / 515.0 <= ratio < 512.0 / 515.0 * (1 + 1e-6), (key, ratio)
+    elif workload == "sine_f32":
+        assert n % 4096 == 0 and abs(ratio - want) < 1e-12, (key, ratio, want)
+    else:
+        assert abs(ratio - want) < 1e-9 * want, (key, ratio, want)
 
 
 def traffic_record(tj, algo, workload, L, n):
@@ -283,6 +307,8 @@ def main():
         last = ev.stats_from_raw(scratch.cpu().numpy().view(np.uint64))
         assert int(last[0]) == world * n * args.steps, (int(last[0]), world * n * args.steps)
     ratio = float(v[1]) / float(v[2])
+    if rank == 0 and args.lines % 4096 == 0:
+        check_known_ratio(args.algo, args.workload, L, n, ratio)
 
     kernel_name = kernel_label(mpc, ev, args.algo, L)
 

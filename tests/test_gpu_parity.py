@@ -642,6 +642,41 @@ def test_device_resident_path_and_synth(mpc, oracle, configs, traces):
     assert (ev.stats_from_raw(scratch.cpu().numpy().view(np.uint64)) == ev.stats_vector()).all()
 
 
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_block_and_group_boundaries(mpc, oracle, configs, traces, L):
+    """The lane kernel streams whole 128-line blocks through its rings and hands what is left behind the last whole block
+    (fewer than 128 lines) to the drain copy of the group code; the BDI kernel streams whole groups of 64 lines through
+    its ring and takes the last partial group from plain loads.  Every line count around those boundaries -- 1 line, one
+    short of / exactly / one past a group and a block, several blocks -- device-resident and through the host stager,
+    per-line results and statistics against the oracle."""
+    import torch
+    rng = np.random.default_rng(L)
+    pool = np.concatenate([traces.structured(700, L, seed=5), traces.mixed(300, L), traces.random_u32(200, L),
+                           traces.zeros(30, L), traces.word_same(30, L)])
+    pool = pool[rng.permutation(len(pool))]
+    cfg = configs.probe_config(L)
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 640, 1023, 1024, 1025):
+        lines = pool[:n]
+        d_lines = torch.from_numpy(np.ascontiguousarray(lines)).to("cuda:0")
+        for make_ev, make_o in ((lambda: mpc.VPC(cfg), lambda: oracle.VpcOracle(cfg)), (lambda: mpc.BDI(L), lambda: oracle.BdiOracle(L))):
+            ev, o = make_ev(), make_o()
+            r = o.compress(lines)
+            s_ref, k_ref = r if isinstance(r, tuple) else (r, None)
+            d_s = torch.zeros(n, dtype=torch.int16, device="cuda:0")
+            d_k = torch.zeros(n, dtype=torch.int8, device="cuda:0")
+            ev.compress_device(d_lines.data_ptr(), n, d_s.data_ptr(), d_k.data_ptr())
+            ev.sync()
+            assert (d_s.cpu().numpy().view(np.uint16) == s_ref).all(), (L, n)
+            if k_ref is not None:
+                assert (d_k.cpu().numpy() == k_ref).all(), (L, n)
+            assert (ev.stats_vector() == o.stats_vector()).all(), (L, n)
+            # statistics-only launch (another instantiation of the kernel) on top: every counter doubles
+            v1 = ev.stats_vector()
+            ev.compress_device(d_lines.data_ptr(), n)
+            assert (ev.stats_vector() == 2 * v1).all(), (L, n)
+            ev.close()
+
+
 def test_full_size_properties(mpc, configs, golden_dir):
     """Checks at a BASELINE-scale buffer: per-line outputs of 32 Mi random lines
     against the oracle-made golden list of the lines that do compress; counts add
