@@ -2,9 +2,10 @@
 // configuration has the plane-major scan, RootIndex 0 and "windowed" predictor tables
 // (see mpc_config.h: build_vpc_plan); 32 / 64 / 128 byte lines.  gfx950 / wave64 only.
 //
-// Mapping: one LANE per line.  Lane i of a wave holds the whole line (line0 + i) in
-// W = L/4 registers, fetched with L/16 global_load_dwordx4 (the loads of a wave cover one
-// contiguous 64*L byte span, so every fetched cache line is fully used).  Nothing
+// Mapping: one LANE per line.  Lane i of a wave holds a whole line in W = L/4 registers.  The
+// unrolled-sequence kernels bring groups of 64 lines from global memory straight into a per-wave
+// ring in LDS (LDS-DMA, mpc_ring.h) and read them out one line per lane; the run-time module loop
+// loads its lines with L/16 global_load_dwordx4 per lane.  Nothing
 // crosses lanes: the per-line predicates are per-lane booleans, a __ballot of one gives
 // the wave-uniform decisions (skip the prediction modules of an all-zero wave, skip a
 // module that cannot win anywhere in the wave, skip the encoder when every line is
