@@ -98,6 +98,7 @@ print("AB " + json.dumps(res), flush=True)
 
 def run(args):
     rounds, workloads, algo, lines, steps = 2, "random_u32,sine_f32,mixed", "VPC", 256 << 20, 8
+    nocheck = False
     names = []
     it = iter(args)
     for a in it:
@@ -106,14 +107,15 @@ def run(args):
         elif a == "--algo": algo = next(it)
         elif a == "--lines": lines = int(next(it))
         elif a == "--steps": steps = int(next(it))
+        elif a == "--no-check": nocheck = True          # timing ablations (results are wrong by design)
         else: names.append(a)
     table = {}
     for r in range(rounds):
         for name in names:
             so = os.path.join(OUT, f"libmpc_hip_{name}.so") if name != "tree" else os.path.join(ROOT, "cal_22-mpc_amd", "libmpc_hip.so")
             env = dict(os.environ, MPC_HIP_LIB=so, MPC_ROOT=ROOT, AB_NAME=name, AB_ALGO=algo, AB_WORKLOADS=workloads,
-                       AB_LINES=str(lines), AB_STEPS=str(steps), AB_CHECK="1" if r == 0 else "0")
-            if r == 0:
+                       AB_LINES=str(lines), AB_STEPS=str(steps), AB_CHECK="1" if (r == 0 and not nocheck) else "0")
+            if r == 0 and not nocheck:
                 # parity once more with the grid capped to 3 workgroups (a wave then walks many groups of lines: ring
                 # stages are reused, queues fill and drain), in a process of its own: the cap is read once per process
                 so_t = so[:-3] + "_t.so"
