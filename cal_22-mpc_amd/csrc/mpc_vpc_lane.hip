@@ -325,15 +325,26 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
     u32 r[W], root_r;
     lane_residue<W, KIND>(c, P.fm[Q], lane_tab(P), r, root_r);
     const u32 z = lane_leading_zero_rows<W>(r);
-    // ties go to the later module (VPC.cpp:389)
-    const u32 m = (!any_full || best.z <= z) ? ~0u : 0u;
-    best.z = mask_sel(m, z, best.z);
-    best.q = (int)mask_sel(m, (u32)Q, (u32)best.q);
-    best.root_r = mask_sel(m, root_r, best.root_r);
-    best.cx = mask_sel(m, (u32)P.fm[Q].cx, best.cx);
-    best.encb = mask_sel(m, (u32)P.enc_bits[P.start + Q + 1], best.encb);
+    if (!any_full) {
+      // the first module evaluated for the group (wave-uniform): it is the winner so far, nothing to select
+      best.z = z;
+      best.q = Q;
+      best.root_r = root_r;
+      best.cx = (u32)P.fm[Q].cx;
+      best.encb = (u32)P.enc_bits[P.start + Q + 1];
 #pragma unroll
-    for (int e = 0; e < W; e++) best.r[e] = mask_sel(m, r[e], best.r[e]);
+      for (int e = 0; e < W; e++) best.r[e] = r[e];
+    } else {
+      // ties go to the later module (VPC.cpp:389)
+      const u32 m = best.z <= z ? ~0u : 0u;
+      best.z = mask_sel(m, z, best.z);
+      best.q = (int)mask_sel(m, (u32)Q, (u32)best.q);
+      best.root_r = mask_sel(m, root_r, best.root_r);
+      best.cx = mask_sel(m, (u32)P.fm[Q].cx, best.cx);
+      best.encb = mask_sel(m, (u32)P.enc_bits[P.start + Q + 1], best.encb);
+#pragma unroll
+      for (int e = 0; e < W; e++) best.r[e] = mask_sel(m, r[e], best.r[e]);
+    }
     any_full = true;
   }
   if constexpr (!last) lane_seq<W, NPT, Q + 1, REST...>(c, P, keep_bits, best, any_full);
@@ -514,14 +525,24 @@ __device__ __forceinline__ void lane_seq_runtime(const Lane<W> &c, const MpcVpcP
     }
     lane_residue_rt<W, W>(c, P, fm, r, root_r);
     const u32 z = P.byte_major ? lane_leading_zero_rows_bm<W, W>(r, scan_mask, 2u * W) : lane_leading_zero_rows<W>(r, scan_mask);
-    const u32 m = (last || z > best.z) ? ~0u : 0u;
-    best.z = mask_sel(m, z, best.z);
-    best.q = (int)mask_sel(m, (u32)q, (u32)best.q);
-    best.root_r = mask_sel(m, root_r, best.root_r);
-    best.cx = mask_sel(m, (u32)fm.cx, best.cx);
-    best.encb = mask_sel(m, (u32)P.enc_bits[P.start + q + 1], best.encb);
+    if (last) {       // (wave-uniform) the first module evaluated: the winner so far
+      best.z = z;
+      best.q = q;
+      best.root_r = root_r;
+      best.cx = (u32)fm.cx;
+      best.encb = (u32)P.enc_bits[P.start + q + 1];
 #pragma unroll
-    for (int e = 0; e < W; e++) best.r[e] = mask_sel(m, r[e], best.r[e]);
+      for (int e = 0; e < W; e++) best.r[e] = r[e];
+    } else {
+      const u32 m = z > best.z ? ~0u : 0u;
+      best.z = mask_sel(m, z, best.z);
+      best.q = (int)mask_sel(m, (u32)q, (u32)best.q);
+      best.root_r = mask_sel(m, root_r, best.root_r);
+      best.cx = mask_sel(m, (u32)fm.cx, best.cx);
+      best.encb = mask_sel(m, (u32)P.enc_bits[P.start + q + 1], best.encb);
+#pragma unroll
+      for (int e = 0; e < W; e++) best.r[e] = mask_sel(m, r[e], best.r[e]);
+    }
   }
 }
 
@@ -858,12 +879,30 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
       }
       return;
     }
-    u32 w[W];
-    const u32 km = keep ? ~0u : 0u;
+    if (keep_mask == need_mask) {
+      // every line that needed the modules keeps its encoding (wave-uniform; the usual case on compressible data): the
+      // winner's residues as they are, nothing to select
+      const u32 w0 = mask_sel(0xffu, best.root_r, best.r[0]);
+      u32 a0 = sum_bytes(w0, 0u), q0 = sum_sq_bytes(w0, 0u), a1 = 0, q1 = 0;
 #pragma unroll
-    for (int e = 0; e < W; e++) w[e] = mask_sel(km, best.r[e], c.x[e]);
-    w[0] = mask_sel(km & 0xffu, best.root_r, w[0]);
-    byte_sums<W>(w, sum_r, sum_r2);
+      for (int e = 1; e < W; e += 2) {
+        a1 = sum_bytes(best.r[e], a1);
+        q1 = sum_sq_bytes(best.r[e], q1);
+        if (e + 1 < W) {
+          a0 = sum_bytes(best.r[e + 1], a0);
+          q0 = sum_sq_bytes(best.r[e + 1], q0);
+        }
+      }
+      sum_r = a0 + a1;
+      sum_r2 = q0 + q1;
+    } else {
+      u32 w[W];
+      const u32 km = keep ? ~0u : 0u;
+#pragma unroll
+      for (int e = 0; e < W; e++) w[e] = mask_sel(km, best.r[e], c.x[e]);
+      w[0] = mask_sel(km & 0xffu, best.root_r, w[0]);
+      byte_sums<W>(w, sum_r, sum_r2);
+    }
     sum_r = need ? sum_r : 0u;
     sum_r2 = need ? sum_r2 : 0u;
     if (need) {
