@@ -966,6 +966,7 @@ int mpc_config_describe(const char *json_text, char *out, size_t cap)
     for (size_t i = 0; i < cfg.enc_bits.size(); i++) s += (i ? ", " : "") + std::to_string(cfg.enc_bits[i]);
     s += "], \"path\": \"" + std::string(plan.fast ? "fast" : "generic") + "\", \"why_generic\": \"" + plan.why_generic +
          "\", \"sequence\": \"" + std::string(!plan.fast ? "" : (mpc_vpc_lane_unrolled(&plan.params) ? "unrolled" : "run-time loop")) +
+         "\", \"general_layout\": \"" + std::string(plan.fast && mpc_vpc_lane_unrolled(&plan.params) && plan.params.gen_layout ? "yes" : "no") +
          "\", \"scan_order\": \"" + std::string(!plan.fast ? "" : (plan.params.byte_major ? "byte-major" : "plane-major")) +
          "\", \"modules\": [";
     for (int i = 0; i < cfg.M; i++) {

@@ -286,9 +286,15 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     P.byte_major = bm0 ? 1 : 0;
     if (bm0) P.runtime_only = 1;
     // any root for OneBase / DiffBase / WeightBase: the residue array is the natural one with bytes 0..root
-    // rotated by one position (ResidueModule.cpp:24-39); run-time module loop only
+    // rotated by one position (ResidueModule.cpp:24-39).  Roots 1..15 (the rotation stays inside the first row of
+    // the scanned array) and tables that stop after a whole number of bit planes run on the unrolled kernels'
+    // general-layout twins; anything else on the run-time module loop
     f.root = m.root;
-    if (m.root != 0 || m.table_size != 8 * L) P.runtime_only = 1;
+    if (m.root != 0 || m.table_size != 8 * L) {
+      const bool whole_planes = m.table_size == 8 * L || (m.table_size >= L && m.table_size % L == 0);
+      if (m.root <= 15 && whole_planes && !bm0) P.gen_layout = 1;
+      else P.runtime_only = 1;
+    }
     f.cx = m.consecutive_xor ? 1 : 0;
     f.tab_off = (int32_t)plan.tab.size();
     if (m.pred_kind == PRED_ONEBASE) { f.kind = MPC_FK_ONEBASE; continue; }
@@ -298,7 +304,7 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     // (BaseIndexTable[i] = i - 8), which the lane-per-line kernel serves straight from registers
     std::vector<uint32_t> sel((size_t)W, 0), c1((size_t)W, 0), c2((size_t)W, 0);
     int shifts[2] = {0, 0}, nshift = 0;
-    bool stride2 = L >= 16 && m.root == 0;
+    bool stride2 = L >= 16 && m.root < 8;       // (words 0 and 1 have table entries of their own)
     for (int i = 8; i < L; i++) stride2 = stride2 && m.base[(size_t)i] == i - 8;
     for (int i = 0; i < L && plan.fast; i++) {
       const int w = i / 4, k = i % 4;
@@ -371,6 +377,12 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
         if (c1[w] != c1[2 + (w & 1)] || c2[w] != c2[2 + (w & 1)]) { no(tag + "BaseIndexTable i-8 with constants that do not repeat every 8 bytes"); break; }
       if (!plan.fast) break;
     }
+  }
+  if (P.runtime_only) P.gen_layout = 0;
+  P.plane_mask = ~0u;
+  if (plan.fast && cfg.n_pred > 0 && !P.byte_major) {
+    const int ts = cfg.modules[(size_t)cfg.start].table_size;
+    if (ts >= L && ts % L == 0 && ts < 8 * L) P.plane_mask = ((0xff00u >> (ts / L)) & 0xffu) * 0x01010101u;
   }
   P.trunc_off = -1;
   if (plan.fast && cfg.n_pred > 0 && cfg.modules[(size_t)cfg.start].table_size != 8 * L) {

@@ -25,7 +25,8 @@ struct MpcFastModule {
   int32_t ls1, rs1;   /* WEIGHT: first shift class  ((b << ls1) >> rs1) & c1 */
   int32_t ls2, rs2;   /* WEIGHT: second shift class ((b << ls2) >> rs2) & c2 */
   int32_t tab_off;    /* DIFF/WEIGHT: dword offset of {sel, c1, c2, c1 & 0x7f.., c1 & 0x80..}[L/4 each] in tab */
-  int32_t root;       /* RootIndex (0 on the unrolled kernels; any position for ONEBASE / DIFF / WEIGHT* on the run-time loop) */
+  int32_t root;       /* RootIndex (0 on the plain unrolled kernels, 0..15 on their general-layout twins; any position for
+                         ONEBASE / DIFF / WEIGHT* on the run-time loop) */
   int32_t prev_word;  /* DIFF/WEIGHT periodic tables.  1: every base byte of words 1.. is the same byte of the
                          previous word (BaseIndexTable[i] = i - 4) and the table entries of words 1.. are
                          identical: no v_perm_b32, two table entries instead of L/4.  2: the same two words
@@ -54,7 +55,8 @@ struct MpcVpcParams {
   int32_t start;        /* module index of the first PredComp module (1 or 2) */
   int32_t has_aws;      /* module 1 is AllWordSame */
   int32_t hist_bins;    /* bins per cluster */
-  int32_t runtime_only; /* fast path, but only through the run-time module loop: a RootIndex != 0 or a truncated scan table */
+  int32_t runtime_only; /* fast path, but only through the run-time module loop: a RootIndex above 15, a scan table truncated
+                           inside a bit plane, the byte-major order */
   int32_t tab_words;    /* number of dwords in tab */
   int32_t trunc_off;    /* truncated plane-major scan table (TableSize < 8 L, the same for every module): dword offset in
                            tab of L/4 mask words (the bits of the XORed residue bytes that are scanned); -1: full table */
@@ -66,7 +68,11 @@ struct MpcVpcParams {
   const uint32_t *tab;  /* fast path dword tables (device) */
   const uint8_t *gtab;  /* generic path byte tables (device) */
   int32_t gtab_bytes;   /* size of gtab; the generic kernel keeps a copy in LDS when it fits */
-  int32_t reserved2;
+  int32_t gen_layout;   /* 1: some RootIndex is 1..15 and / or the plane-major scan table stops after a whole number of bit
+                           planes (TableSize = k L, k = 1..7): the unrolled kernels' general-layout twins take it */
+  uint32_t plane_mask;  /* the scanned bit planes of a residue byte, in every byte (0xffffffff: all; TableSize = 6 L: 0xfcfcfcfc);
+                           meaningful when trunc_off < 0 or gen_layout */
+  int32_t reserved3;
 };
 
 /* Device-side raw statistics (uint64 each):

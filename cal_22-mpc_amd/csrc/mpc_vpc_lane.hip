@@ -56,7 +56,47 @@ struct Lane {
   u32 x[W];    // the line
   u32 b0;      // byte 0 = root (RootIndex 0)
   u32 rootb;   // root replicated into 4 bytes
+  bool gen;    // a constant of the instantiation: general layout (a RootIndex of 1..15 per module, whole-plane truncation)
 };
+
+// ---- general layout (the GEN twins of the unrolled kernels) ---------------------------------------------------------
+// RootIndex 1..15 (OneBase / DiffBase / WeightBase; wave-uniform, read from the module's parameters).  The predictors
+// work on the natural byte positions and leave the RAW root byte in the natural residue (the tables force the predicted
+// byte to 0 there); ResidueModule.cpp:24-39 then moves the root to the front, i.e. bytes 0..root rotate by one position.
+// With the root inside the first 16 bytes that rotation stays inside residue words 0..3 = row 0 of every bit plane, so
+//  * the row-0 prefilters need no rotation at all (they OR the MSBs of bytes 0..15: the same set of bytes),
+//  * a full evaluation rotates four words (two instructions each).
+// line[root] in every byte
+template <int W>
+__device__ __forceinline__ u32 lane_root_bytes(const Lane<W> &c, int root)
+{
+  // OR of masked words: a select chain here is turned into an indexed read of a copy of x[] in scratch memory
+  const int rw = root >> 2;
+  u32 xw = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++) xw = and_or(c.x[e], 0u - (u32)(e == rw), xw);
+  return perm(xw, xw, 0x01010101u * (u32)(root & 3));
+}
+// what OneBase predicts for word e: line[root] everywhere, 0 at the root position itself
+__device__ __forceinline__ u32 lane_onebase_pred(u32 rb, int root, int e)
+{
+  const u32 here = (e == (root >> 2)) ? (0xffu << (8 * (root & 3))) : 0u;      // (scalar)
+  return rb & ~here;
+}
+// natural residue -> root-first order, words 0..NR-1 (NR <= 4 suffices: root <= 15)
+template <int W, int NR>
+__device__ __forceinline__ void lane_root_to_front(const Lane<W> &c, int root, u32 (&r)[W])
+{
+  u32 prev = lane_root_bytes<W>(c, root) & 0xff000000u;      // the raw root enters byte 0 of word 0
+#pragma unroll
+  for (int e = 0; e < (NR < 4 ? NR : 4); e++) {
+    const u32 sh = alignbyte(r[e], prev, 3);                   // the natural bytes one position up
+    const int nb = root + 1 - 4 * e;                           // bytes of this word at positions <= root
+    const u32 m = nb >= 4 ? ~0u : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+    prev = r[e];
+    r[e] = mask_sel(m, sh, r[e]);
+  }
+}
 
 // bit 7 of every byte = MSB of the per-byte difference a - b (the other bits are junk)
 __device__ __forceinline__ u32 msb_of_bsub(u32 a, u32 b) { return ((a | H80) - (b & L7F)) ^ a ^ ~b; }
@@ -129,10 +169,16 @@ __device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModu
 {
   root_r = 0;
   if constexpr (lk_base(KIND) == MPC_FK_ONEBASE) {
-    // predicted = line[0] everywhere; position 0 of the residue array is the raw root
-    r[0] = bsub(c.x[0], c.rootb & 0xffffff00u);
+    if (c.gen && fm.root != 0) {       // (wave-uniform; GEN twins only)
+      const u32 rb = lane_root_bytes<W>(c, fm.root);
 #pragma unroll
-    for (int e = 1; e < NR; e++) r[e] = bsub(c.x[e], c.rootb);
+      for (int e = 0; e < NR; e++) r[e] = bsub(c.x[e], e < 4 ? lane_onebase_pred(rb, fm.root, e) : rb);
+    } else {
+      // predicted = line[0] everywhere; position 0 of the residue array is the raw root
+      r[0] = bsub(c.x[0], c.rootb & 0xffffff00u);
+#pragma unroll
+      for (int e = 1; e < NR; e++) r[e] = bsub(c.x[e], c.rootb);
+    }
   } else if constexpr (lk_base(KIND) == MPC_FK_CONSEC) {
     // predicted[i] = inp[i - 1]; predicted byte 0 := 0 keeps the raw root at position 0
     u32 in[NR];
@@ -160,8 +206,14 @@ __device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &
 {
   u32 m = 0;
   if constexpr (lk_base(KIND) == MPC_FK_ONEBASE) {
+    if (c.gen && fm.root != 0) {       // (wave-uniform; GEN twins only)
+      const u32 rb = lane_root_bytes<W>(c, fm.root);
 #pragma unroll
-    for (int e = E0; e < E1; e++) m |= msb_of_bsub(c.x[e], e ? c.rootb : (c.rootb & 0xffffff00u));
+      for (int e = E0; e < E1; e++) m |= msb_of_bsub(c.x[e], lane_onebase_pred(rb, fm.root, e));
+    } else {
+#pragma unroll
+      for (int e = E0; e < E1; e++) m |= msb_of_bsub(c.x[e], e ? c.rootb : (c.rootb & 0xffffff00u));
+    }
   } else if constexpr (lk_base(KIND) == MPC_FK_CONSEC) {
 #pragma unroll
     for (int e = E0; e < E1; e++) {
@@ -179,8 +231,9 @@ __device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &
 // Leading zero rows of the scanned array (row = plane * W/4 + column group).  The first
 // non-zero row of the XORed planes equals that of the raw residue planes (DESIGN.md
 // "Selector on raw residues"), so the selector works on r directly.
+// plane_mask: the scanned bit planes, in every byte (GEN twins: a table that stops after whole planes; else all ones)
 template <int W>
-__device__ __forceinline__ u32 lane_leading_zero_rows(const u32 (&r)[W], ctab_t scan_mask = nullptr)
+__device__ __forceinline__ u32 lane_leading_zero_rows(const u32 (&r)[W], ctab_t scan_mask = nullptr, u32 plane_mask = ~0u)
 {
   constexpr int NG = W / 4;
   u32 S[NG], G = 0;
@@ -199,12 +252,13 @@ __device__ __forceinline__ u32 lane_leading_zero_rows(const u32 (&r)[W], ctab_t 
       G |= S[j];
     }
   }
-  const u32 p = (u32)__clz((int)fold8(G)) - 24u;     // first non-zero plane (0 = MSB); 8 if G == 0
+  const u32 gf = fold8(G) & plane_mask;              // (& 0xff of the mask: fold8 leaves one byte)
+  const u32 p = (u32)__clz((int)gf) - 24u;           // first non-zero scanned plane (0 = MSB); 8 if none
   const u32 B = H80 >> (p & 7u);                      // that plane's bit in every byte
   u32 j_star = NG - 1;
 #pragma unroll
   for (int j = NG - 2; j >= 0; j--) j_star = (S[j] & B) ? (u32)j : j_star;
-  return G ? NG * p + j_star : 2u * W;
+  return (plane_mask == ~0u ? G : gf) ? NG * p + j_star : 2u * W;
 }
 
 template <int W>
@@ -324,7 +378,8 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
   if (last || (keep_bits & (1u << Q))) {
     u32 r[W], root_r;
     lane_residue<W, KIND>(c, P.fm[Q], lane_tab(P), r, root_r);
-    const u32 z = lane_leading_zero_rows<W>(r);
+    if (c.gen && P.fm[Q].root != 0) lane_root_to_front<W, W>(c, P.fm[Q].root, r);
+    const u32 z = lane_leading_zero_rows<W>(r, nullptr, c.gen ? P.plane_mask : ~0u);
     if (!any_full) {
       // the first module evaluated for the group (wave-uniform): it is the winner so far, nothing to select
       best.z = z;
@@ -359,6 +414,7 @@ __device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &
 {
   if constexpr (Q + 1 == NPT) {
     lane_residue<W, KIND>(c, P.fm[Q], lane_tab(P), best.r, best.root_r);
+    if (c.gen && P.fm[Q].root != 0) lane_root_to_front<W, W>(c, P.fm[Q].root, best.r);
     best.q = Q;
     best.cx = (u32)P.fm[Q].cx;
     best.encb = (u32)P.enc_bits[P.start + Q + 1];
@@ -758,7 +814,7 @@ __device__ __forceinline__ void lane_run_add(LaneRun &rs, u32 key, u32 sum_r, u3
 // the wave's queue (qn = entries waiting, wave-uniform).  Drain groups (DRAIN = true): this lane
 // evaluates queued line `dline` if `dvalid`, with every module it needs.
 // loff: this lane of a streaming group evaluates line line0 + loff; alt: see lane_prefilters.
-template <int W, bool OUT, bool FULL, bool DRAIN, int... KINDS>
+template <int W, bool OUT, bool GEN, bool FULL, bool DRAIN, int... KINDS>
 __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u32 loff, u32 dline, bool dvalid,
                                           const MpcVpcParams &P, const LaneEnv &E, LaneRun &rs, u32 &qn, bool &alt)
 {
@@ -771,6 +827,7 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
   const u64 valid_mask = (FULL && !DRAIN) ? ~0ull : __ballot(valid);
   bool deferred = false;
   Lane<W> c;
+  c.gen = GEN;
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
     c.x[4 * i] = v[i].x; c.x[4 * i + 1] = v[i].y; c.x[4 * i + 2] = v[i].z; c.x[4 * i + 3] = v[i].w;
@@ -841,6 +898,10 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
     if (NPT == 0 && scan_mask) {
 #pragma unroll
       for (int e = 0; e < W; e++) t[e] &= scan_mask[e];
+    }
+    if (GEN && P.plane_mask != ~0u) {      // (wave-uniform) a table that stops after whole bit planes: the others are not scanned
+#pragma unroll
+      for (int e = 0; e < W; e++) t[e] &= P.plane_mask;
     }
     // The certificate pays where it closes every line of the group (incompressible data); where the
     // previous group of this wave still had compressible lines it is skipped and the encoder runs
@@ -1004,11 +1065,11 @@ static LaneLds lane_lds_plan(const MpcVpcParams *P, int wpb, bool wants_queue)
 #define MPC_LB_WAVES_128 2
 #endif
 // ring_cfg: ring stages per wave (bits 0..7) | queue entries per wave << 8 (lane_lds_plan; the run-time loop ignores it)
-template <int W, bool OUT, int... KINDS>
-__global__ void __launch_bounds__((64 * lane_wpb<W, sizeof...(KINDS)>()),
-                                  (W <= 16 ? (sizeof...(KINDS) > 0 ? (W == 8 && MPC_LANE_WAVES_32 == 10 ? 5 : MPC_LB_WAVES) : MPC_LB_WAVES_RT) : MPC_LB_WAVES_128))
-vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
-                uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats, u32 ring_cfg)
+// GEN: the general-layout twin (vpc_lane_gen_kernel): RootIndex 0..15 per module, scan tables that stop after a whole
+// number of bit planes.  The plain kernels keep their code (and their names in the profiles) untouched.
+template <int W, bool OUT, bool GEN, int... KINDS>
+__device__ __forceinline__ void vpc_lane_body(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, const MpcVpcParams &P,
+                                              uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats, u32 ring_cfg)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NQ = W / 4;             // 16-byte pieces per line
@@ -1048,7 +1109,7 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
     if (line0 < n_lines) lane_fetch<NQ>(va, lines, line0 + E.lane, n_lines);
     while (line0 < n_lines) {
       lane_fetch<NQ>(vb, lines, line0 + stride + E.lane, n_lines);
-      lane_step<W, OUT, false, false>(va, line0, E.lane, 0u, true, P, E, rs, qn, alt);
+      lane_step<W, OUT, false, false, false>(va, line0, E.lane, 0u, true, P, E, rs, qn, alt);
       line0 += stride;
 #pragma unroll
       for (int i = 0; i < NQ; i++) va[i] = vb[i];
@@ -1133,7 +1194,7 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
           }
           __builtin_amdgcn_sched_barrier(0);                              // (the requests go out before the arithmetic, not after it)
           // (one call site: the group code is large)
-          lane_step<W, OUT, true, false, KINDS...>(va, pair_now ? cb * 128u + h : cb * 128u + h * 64u, pair_now ? 2u * E.lane : E.lane,
+          lane_step<W, OUT, GEN, true, false, KINDS...>(va, pair_now ? cb * 128u + h : cb * 128u + h * 64u, pair_now ? 2u * E.lane : E.lane,
                                                    0u, true, P, E, rs, qn, alt);
           if ((++iter & 255u) == 0) {   // wave-uniform: keeps the 32-bit accumulators far from overflow
             lane_run_flush(rs, E.st, E.K, E.bins);
@@ -1186,7 +1247,7 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
           break;
         }
         lane_fetch<NQ>(va, lines, dline, n_lines);
-        lane_step<W, OUT, false, true, KINDS...>(va, 0u, 0u, dline, dvalid, P, E, rs, qn, alt);
+        lane_step<W, OUT, GEN, false, true, KINDS...>(va, 0u, 0u, dline, dvalid, P, E, rs, qn, alt);
       }
       if (tail_mine) tail_done = true;
       if (cb == kNone && (tail_done || blockIdx.x != gridDim.x - 1u || wave != 0u)) break;
@@ -1194,6 +1255,24 @@ vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, Mp
   }
   lane_run_flush(rs, E.st, E.K, E.bins);
   stats_flush(E.st, E.K, E.bins, gstats, (int)(E.lane + 64u * wave), 64 * (int)WPB);
+}
+
+#define MPC_LANE_BOUNDS(W, NPT)                                                                                     \
+  __launch_bounds__((64 * lane_wpb<W, NPT>()),                                                                      \
+                    (W <= 16 ? (NPT > 0 ? (W == 8 && MPC_LANE_WAVES_32 == 10 ? 5 : MPC_LB_WAVES) : MPC_LB_WAVES_RT) : MPC_LB_WAVES_128))
+template <int W, bool OUT, int... KINDS>
+__global__ void MPC_LANE_BOUNDS(W, (sizeof...(KINDS)))
+vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
+                uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats, u32 ring_cfg)
+{
+  vpc_lane_body<W, OUT, false, KINDS...>(lines, n_lines, first_line, P, sizes_out, sel_out, gstats, ring_cfg);
+}
+template <int W, bool OUT, int... KINDS>
+__global__ void MPC_LANE_BOUNDS(W, (sizeof...(KINDS)))
+vpc_lane_gen_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
+                    uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats, u32 ring_cfg)
+{
+  vpc_lane_body<W, OUT, true, KINDS...>(lines, n_lines, first_line, P, sizes_out, sel_out, gstats, ring_cfg);
 }
 
 #define OB MPC_FK_ONEBASE
@@ -1223,6 +1302,14 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
 {
   // OUT = per-line outputs requested (parity mode); the statistics-only build has no output code
   // histograms of many clusters x bins need more than the 64 KiB of LDS a kernel gets by default
+#define MPC_LAUNCH_K(KERNEL, WV, OUTV)                                                                               \
+  {                                                                                                                \
+    if (smem > (64u << 10))                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<WV, OUTV, KINDS...>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                            \
+    hipLaunchKernelGGL((KERNEL<WV, OUTV, KINDS...>), dim3(wgrid), dim3(64 * wpb), smem, stream, l, n_lines,         \
+                       first_line, *P, d_sizes, d_sel, d_stats, ring_cfg);                                         \
+  }
 #define MPC_LAUNCH(WV)                                                                                              \
   {                                                                                                                \
     constexpr int wpb = lane_wpb<WV, sizeof...(KINDS)>();                                                          \
@@ -1244,18 +1331,16 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
       wgrid = (int)(want < cap ? want : cap);                                                                      \
       if (wgrid < 1) wgrid = 1;                                                                                    \
     }                                                                                                              \
-    if (d_sizes || d_sel) {                                                                                        \
-      if (smem > (64u << 10))                                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_lane_kernel<WV, true, KINDS...>),            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
-      hipLaunchKernelGGL((vpc_lane_kernel<WV, true, KINDS...>), dim3(wgrid), dim3(64 * wpb), smem, stream, l,      \
-                         n_lines, first_line, *P, d_sizes, d_sel, d_stats, ring_cfg);                              \
-    } else {                                                                                                       \
-      if (smem > (64u << 10))                                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vpc_lane_kernel<WV, false, KINDS...>),           \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
-      hipLaunchKernelGGL((vpc_lane_kernel<WV, false, KINDS...>), dim3(wgrid), dim3(64 * wpb), smem, stream, l,     \
-                         n_lines, first_line, *P, d_sizes, d_sel, d_stats, ring_cfg);                              \
+    const bool out = d_sizes || d_sel;                                                                             \
+    bool gen_done = false;                                                                                         \
+    if constexpr (sizeof...(KINDS) > 0) {                                                                          \
+      if (P->gen_layout) {                                                                                         \
+        if (out) MPC_LAUNCH_K(vpc_lane_gen_kernel, WV, true) else MPC_LAUNCH_K(vpc_lane_gen_kernel, WV, false)     \
+        gen_done = true;                                                                                           \
+      }                                                                                                            \
+    }                                                                                                              \
+    if (!gen_done) {                                                                                                       \
+      if (out) MPC_LAUNCH_K(vpc_lane_kernel, WV, true) else MPC_LAUNCH_K(vpc_lane_kernel, WV, false)               \
     }                                                                                                              \
   }
   switch (P->L) {
@@ -1273,6 +1358,7 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
   default: return hipErrorInvalidValue;
   }
 #undef MPC_LAUNCH
+#undef MPC_LAUNCH_K
   return hipGetLastError();
 }
 

@@ -258,6 +258,61 @@ def test_vpc_fast_path_nonzero_root_and_truncated_scan(mpc, oracle, configs, tra
     _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:1500], expect_path=mpc.MPC_PATH_VPC_GENERIC)
 
 
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_vpc_general_layout_twins(mpc, oracle, configs, traces, L):
+    """RootIndex 1..15 and scan tables that stop after a whole number of bit planes (TableSize = k L) keep the UNROLLED
+    kernels (their general-layout twins, vpc_lane_gen_kernel: the same row-0 prefilters and line ring; round 2 sent these
+    to the run-time module loop at 0.27-0.33 of the peak).  Module sequences with an instantiation: the probe's four
+    predictors with 4- and 8-byte-back tables, their non-periodic form (a root outside word 0 breaks the period), single
+    models.  With per-line outputs and in statistics-only mode; a root above 15 or a table cut inside a plane still takes
+    the run-time loop.  ResidueModule.cpp:24-39 (root first), ScanModule.cpp:13-19 (untouched cells stay zero)."""
+    rng = np.random.default_rng(300 + L)
+    lines = np.concatenate([traces.structured(5000, L, seed=23), traces.mixed(2500, L), traces.random_u32(800, L),
+                            traces.sine_f32(1024, L), traces.counters_u32(500, L), traces.zeros(70, L), traces.word_same(70, L)])
+    lines = lines[rng.permutation(len(lines))]
+    az, aws = {"name": "AllZero"}, {"name": "AllWordSame"}
+
+    def trunc(ts):
+        return None if ts is None else {"TableSize": ts, "Rows": [i // L for i in range(ts)], "Cols": [i % L for i in range(ts)]}
+    prev4 = [max(i - 4, 0) for i in range(L)]
+    prev8 = [max(i - 8, 0) for i in range(L)]
+    w2 = [[1.0, 0.5][i % 2] for i in range(L)]
+    d1 = [1 if i % 4 == 0 else 0 for i in range(L)]
+
+    def probe(roots, ts, prev=prev4):
+        s = trunc(ts)
+        return configs.make_config(L, [az, aws, configs.one_base(L, roots[0], True, s), configs.consecutive_base(L, 0, True, s),
+                                       configs.diff_base(L, prev, d1, roots[1], False, s), configs.weight_base(L, prev, w2, roots[2], True, s)])
+
+    def check(cfg, general, n=len(lines)):
+        d = mpc.describe_config(cfg)
+        assert d["path"] == "fast" and d["general_layout"] == ("yes" if general else "no"), d
+        assert d["sequence"] == ("unrolled" if general else "run-time loop"), d
+        _check_vpc(mpc, oracle, cfg, lines[:n], expect_path=mpc.MPC_PATH_VPC_FAST)
+        ev = mpc.VPC(cfg)                                   # the kernels without per-line outputs
+        ev.compress_lines(lines[:n], want_sizes=False, want_selected=False)
+        o = oracle.VpcOracle(cfg)
+        o.compress(lines[:n])
+        assert (ev.stats_vector() == o.stats_vector()).all()
+        ev.close()
+
+    # roots inside word 0 keep the periodic tables; every whole-plane table size; both at once
+    for roots, ts in (((5, 3, 2), None), ((0, 0, 0), 6 * L), ((15, 1, 3), 7 * L), ((1, 0, 0), L), ((12, 2, 1), 3 * L),
+                      ((4, 3, 0), None), ((8, 0, 2), 2 * L), ((0, 3, 3), 4 * L), ((2, 0, 0), 5 * L)):
+        check(probe(roots, ts), True, 6000)
+    check(probe((7, 5, 6), 5 * L, prev8), True, 6000)        # 8-byte-back tables, roots inside the first element
+    check(probe((3, 6, 9), None), True, 6000)                # roots outside word 0: the non-periodic instantiation
+    check(probe((9, 13, 15), 6 * L), True)
+    # single models
+    for mods in ([az, aws, configs.one_base(L, 11, True, trunc(6 * L))], [az, configs.diff_base(L, prev4, d1, 2, True)],
+                 [az, aws, configs.weight_base(L, prev8, w2, 5, False, trunc(3 * L))], [az, aws, configs.one_base(L, 7, False), configs.consecutive_base(L, 0, True)]):
+        check(configs.make_config(L, mods), True, 5000)
+    # outside the twins' reach: the run-time loop
+    check(probe((16, 0, 0), None), False, 3000)
+    check(probe((0, 0, 0), 6 * L + 8), False, 3000)
+    check(probe((0, 0, 0), 16), False, 3000)
+
+
 def test_vpc_many_modules_large_histogram(mpc, oracle, configs, traces):
     """16 modules at 128-byte lines: 17 clusters x 1030 bins = 70 KB of LDS histogram, more than a
     kernel's default 64 KiB (fast kernel with the run-time module loop, and the generic kernel)."""
