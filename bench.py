@@ -100,6 +100,65 @@ def cpu_baseline(configs, traces, workload: str, L: int, seconds: float = 12.0, 
             "single_core_blocks_per_s": rate1}
 
 
+class PowerProbe:
+    """Board power and shader clock while a kernel runs back to back (OUTSIDE the timed region): the device's hwmon files
+    (power1_input in microwatts, freq1_input = sclk in Hz, power1_cap) found through its PCI address, read every 10 ms
+    from a thread.  DESIGN.md 4.1: the BASELINE workloads run at the board's power cap, which is what holds their clock --
+    and with it the achieved fraction of the HBM peak -- down.  None when the files are not there."""
+
+    def __init__(self, torch, device_index: int):
+        import glob
+        self.dir = None
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            hits = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if hits and os.path.exists(os.path.join(hits[0], "power1_input")):
+                self.dir = hits[0]
+        except Exception:       # noqa: BLE001 -- a reporting extra: never fails the bench
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def run(self, torch, launch, stream, seconds: float = 1.0):
+        if self.dir is None:
+            return None
+        import threading
+        samples, stop = [], [False]
+
+        def sampler():
+            while not stop[0]:
+                samples.append((self._read("power1_input"), self._read("freq1_input")))
+                time.sleep(0.01)
+        th = threading.Thread(target=sampler)
+        t0 = time.perf_counter()
+        launches = 0
+        for _ in range(4):
+            launch()
+        stream.synchronize()
+        th.start()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(8):
+                launch()
+                launches += 1
+            stream.synchronize()
+        stop[0] = True
+        th.join()
+        pw = [a / 1e6 for a, _ in samples if a]
+        ck = [b / 1e6 for _, b in samples if b]
+        cap = self._read("power1_cap")
+        if not pw:
+            return None
+        return {"board_w_mean": sum(pw) / len(pw), "board_w_max": max(pw), "cap_w": cap / 1e6 if cap else None,
+                "sclk_mhz_mean": sum(ck) / len(ck) if ck else None, "samples": len(pw), "seconds": seconds, "launches": launches,
+                "source": "hwmon power1_input / freq1_input of the device, kernel launched back to back after the timed region"}
+
+
 def kernel_label(mpc, ev, algo: str, L: int) -> str:
     if algo == "BDI":
         return f"bdi_kernel<{L // 4}>"
@@ -118,7 +177,7 @@ def make_evaluator(mpc, configs, algo: str, L: int, device: int):
     return {"BDI": mpc.BDI, "FPC": mpc.FPC, "BPC": mpc.BPC}[algo](L, device=device)
 
 
-def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, bytes_total, first_line=0, steps=8):
+def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, bytes_total, first_line=0, steps=8, power=None):
     """One sub-record: `workload` generated into (a prefix of) buf, `steps` launches timed with HIP events on
     the launch stream, the evaluator's own statistics checked for the line count."""
     kind, L = WORKLOADS[workload]
@@ -149,6 +208,8 @@ def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, byte
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": n * L},
            "compression_ratio": float(v[1]) / float(v[2])}
+    if power is not None:
+        rec["power"] = power.run(torch, lambda: ev.compress_device(buf.data_ptr(), n, stream=sp), stream, 0.8)
     ev.close()
     return rec
 
@@ -311,6 +372,8 @@ def main():
         check_known_ratio(args.algo, args.workload, L, n, ratio)
 
     kernel_name = kernel_label(mpc, ev, args.algo, L)
+    power = PowerProbe(torch, local_rank) if world == 1 else None
+    headline_power = power.run(torch, lambda: ev.compress_device(buf.data_ptr(), n, stream=sp), stream, 1.5) if power else None
 
     # ---- sub-records (not part of the timed region above) ----
     # N = 1: every other BASELINE workload through the same entry point, VPC and BDI, 16 GiB each.
@@ -320,7 +383,7 @@ def main():
         for wl, algo in SUB_WORKLOADS:
             if (wl, algo) == (args.workload, args.algo):
                 continue
-            workloads.append(time_workload(torch, mpc, configs, buf, stream, local_rank, wl, algo, n * L))
+            workloads.append(time_workload(torch, mpc, configs, buf, stream, local_rank, wl, algo, n * L, power=power))
     # N > 1: BASELINE config 4 -- mixed int/fp blocks sharded contiguously over the ranks, one RCCL
     # all-reduce of the statistics per pass -- as its own sub-record next to the primary value (which
     # stays on the N = 1 workload so that the scaling curve is comparable).
@@ -397,6 +460,8 @@ def main():
                          "algorithmic_bytes_per_launch": n * L,
                          "read_probe_gbps": probe_gbps, "frac_of_read_probe": achieved / probe_gbps},
         }
+        if headline_power is not None:
+            out["power"] = headline_power
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(configs, traces, args.workload, L, algo=args.algo)
         else:
