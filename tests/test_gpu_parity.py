@@ -938,6 +938,41 @@ print("ROUTES " + json.dumps(res))
     assert b["bdi_deferred"] > 0 and b["bdi_drains"] > 64 and b["bdi_deferred"] <= 64 * b["bdi_drains"], b
 
 
+def test_general_layout_twins_under_a_capped_grid(oracle, configs, traces, tmp_path):
+    """The general-layout twins (RootIndex 1..15, whole-plane truncation) share the streaming loop of the plain unrolled
+    kernels: with the grid capped to one workgroup (test library) every wave reuses its ring stages hundreds of times,
+    sets lines aside and drains them inside the loop, and switches to paired groups on the alternating trace -- all of it
+    in the twins' copy of the group code.  Results against the oracle; the route counters say the routes ran."""
+    code = r"""
+res = {}
+az, aws = {"name": "AllZero"}, {"name": "AllWordSame"}
+for L in (64, 32, 128):
+    def trunc(ts): return None if ts is None else {"TableSize": ts, "Rows": [i // L for i in range(ts)], "Cols": [i % L for i in range(ts)]}
+    prev4 = [max(i - 4, 0) for i in range(L)]; w2 = [[1.0, 0.5][i % 2] for i in range(L)]; d1 = [1 if i % 4 == 0 else 0 for i in range(L)]
+    n = 120001 if L == 64 else 40003
+    lines = np.concatenate([T.mixed(n, L), T.structured(n // 3, L, seed=3), T.sine_f32(n // 6, L), T.random_u32(n // 5, L), T.mixed(4097, L)])
+    for roots, ts in (((5, 3, 2), None), ((0, 0, 0), 6 * L), ((13, 1, 2), 5 * L)):
+        s_ = trunc(ts)
+        cfg = C.make_config(L, [az, aws, C.one_base(L, roots[0], True, s_), C.consecutive_base(L, 0, True, s_), C.diff_base(L, prev4, d1, roots[1], False, s_),
+                                C.weight_base(L, prev4, w2, roots[2], True, s_)])
+        d = mpc.describe_config(cfg)
+        assert d["sequence"] == "unrolled" and d["general_layout"] == "yes", d
+        ev, o = mpc.VPC(cfg), O.VpcOracle(cfg)
+        s, k = ev.compress_lines(lines)
+        s_ref, k_ref = o.compress(lines)
+        assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all(), (L, roots, ts)
+        res["%d/%s/%s" % (L, roots, ts)] = routes(ev)
+        ev.close()
+print("ROUTES " + json.dumps(res))
+"""
+    res = _run_with_test_library(code, grid_cap=1)
+    for key, r in res.items():
+        assert r["vpc_paired_blocks"] + r["vpc_plain_blocks"] > 0, (key, r)
+        if key.startswith("64/") or key.startswith("32/"):           # (128-byte lines never set lines aside)
+            assert r["vpc_deferred"] > 0 and r["vpc_drains"] > 0, (key, r)
+    assert any(r["vpc_paired_blocks"] > 0 for r in res.values()), res
+
+
 def test_paired_groups_on_alternating_lines(oracle, configs, traces, tmp_path):
     """Where neighbouring lines alternate between two kinds the VPC lane kernel switches a wave to paired groups
     (even lines of a 128-line block, then the odd ones) and probes with plain groups now and then.  With the grid
