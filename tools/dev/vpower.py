@@ -15,7 +15,9 @@ def smi():
         return None
 print("idle", smi(), flush=True)
 for op in ops:
-    pr = subprocess.Popen([os.path.join(here, "vrate"), wps, "40000", op, "2.5"], stdout=subprocess.PIPE, text=True)
+    op, _, lanes = op.partition("@")                  # op@N: only the first N lanes of every wave run
+    pr = subprocess.Popen([os.path.join(here, "vrate"), wps, "40000", op, "2.5", lanes or "0"], stdout=subprocess.PIPE, text=True)
+    op = op + ("@" + lanes if lanes else "")
     time.sleep(1.0)
     got = []
     while pr.poll() is None:

@@ -21,6 +21,7 @@ __global__ void __launch_bounds__(1024) k_##NAME(unsigned *out, int iters, unsig
   unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
   unsigned b = seed * 2654435761u + threadIdx.x, c = seed ^ 0x0c0d0e0fu; unsigned s0 = __builtin_amdgcn_readfirstlane(seed | 0x01020304u); \
   unsigned long long m64 = __builtin_amdgcn_read_exec() ^ (0x5555aaaaull * seed); asm volatile("s_mov_b64 vcc, %0" :: "s"(m64) : "vcc"); \
+  if ((seed >> 16) != 0u && (threadIdx.x & 63u) >= (seed >> 16)) return;      /* only the first (seed >> 16) lanes of every wave run */ \
   for (int i = 0; i < iters; i++) { OP8(S) OP8(S) OP8(S) OP8(S) } \
   if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = a0; }
 
@@ -114,17 +115,18 @@ int main(int argc, char **argv) {
   double base = 0;
   if (argc > 3) {      // sustained mode: one instruction, back to back for argv[4] seconds (power sampling from outside)
     double secs = argc > 4 ? atof(argv[4]) : 2.0;
+    const unsigned seed_arg = 12345u | ((argc > 5 ? (unsigned)atoi(argv[5]) : 0u) << 16);      // argv[5]: active lanes per wave
     for (auto &e : ents) {
       if (strcmp(e.name, argv[3])) continue;
-      hipLaunchKernelGGL(e.fn, dim3(cus * wg_per_cu), dim3(threads), 0, 0, out, iters, 12345u);
+      hipLaunchKernelGGL(e.fn, dim3(cus * wg_per_cu), dim3(threads), 0, 0, out, iters, seed_arg);
       CHK(hipDeviceSynchronize());
       CHK(hipEventRecord(e0));
-      hipLaunchKernelGGL(e.fn, dim3(cus * wg_per_cu), dim3(threads), 0, 0, out, iters, 12345u);
+      hipLaunchKernelGGL(e.fn, dim3(cus * wg_per_cu), dim3(threads), 0, 0, out, iters, seed_arg);
       CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
       float ms1; CHK(hipEventElapsedTime(&ms1, e0, e1));
       int n = (int)(secs * 1000.0 / ms1) + 1;
       CHK(hipEventRecord(e0));
-      for (int r = 0; r < n; r++) hipLaunchKernelGGL(e.fn, dim3(cus * wg_per_cu), dim3(threads), 0, 0, out, iters, 12345u);
+      for (int r = 0; r < n; r++) hipLaunchKernelGGL(e.fn, dim3(cus * wg_per_cu), dim3(threads), 0, 0, out, iters, seed_arg);
       CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
       float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); ms /= n;
       printf("SUSTAIN %s %.4f ms per launch, %.4f ns per wave-instruction per SIMD, %.3f G wave-instructions/s chip-wide\n", e.name, ms,
