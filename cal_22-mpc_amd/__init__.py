@@ -80,6 +80,8 @@ def lib() -> C.CDLL:
             "mpc_get_info": ([H, C.POINTER(Info)], C.c_int),
             "mpc_last_error": ([H], C.c_char_p),
             "mpc_path_reason": ([H], C.c_char_p),
+            "mpc_kernel_form": ([H], C.c_char_p),
+            "mpc_jit_compile_check": ([C.c_char_p, C.c_char_p, C.c_size_t], C.c_longlong),
             "mpc_compress_batch": ([H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p], C.c_int),
             "mpc_compress_batch_device": ([H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
             "mpc_sync": ([H], C.c_int),
@@ -109,7 +111,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "mpc_create_vpc", "mpc_create_vpc_from_string", "mpc_create_bdi", "mpc_create_fpc", "mpc_create_bpc", "mpc_destroy", "mpc_get_info",
-    "mpc_last_error", "mpc_path_reason", "mpc_compress_batch", "mpc_compress_batch_device", "mpc_sync", "mpc_stats_len",
+    "mpc_last_error", "mpc_path_reason", "mpc_kernel_form", "mpc_jit_compile_check", "mpc_compress_batch", "mpc_compress_batch_device", "mpc_sync", "mpc_stats_len",
     "mpc_stats_get", "mpc_stats_merge", "mpc_stats_set", "mpc_stats_reset", "mpc_stats_raw_len",
     "mpc_stats_copy_raw_device", "mpc_stats_from_raw", "mpc_config_describe",
     "mpc_compress_npy", "mpc_npy_shape", "mpc_compress_gpgpusim_log", "mpc_gpgpusim_log_line_size",
@@ -134,6 +136,18 @@ def describe_config(cfg) -> Dict:
     out = json.loads(buf.value.decode())
     out["rc"] = rc
     return out
+
+
+def jit_compile_check(cfg) -> int:
+    """Build check of the run-time compilation (no device needed): when the configuration's module sequence would be compiled
+    with hiprtc at handle creation, compile it now for gfx950 and return the code object's size; 0 when nothing would be
+    compiled.  Raises MpcError with the compiler's log on failure."""
+    text = cfg if isinstance(cfg, str) else json.dumps(cfg)
+    log = C.create_string_buffer(1 << 16)
+    n = lib().mpc_jit_compile_check(text.encode(), log, len(log))
+    if n < 0:
+        raise MpcError(int(n), log.value.decode(errors="replace"))
+    return int(n)
 
 
 class _Evaluator:
@@ -255,6 +269,8 @@ class VPC(_Evaluator):
         self.hist_bins = self.info.hist_bins
         self.kernel_path = self.info.kernel_path
         self.path_reason = (lib().mpc_path_reason(self._h) or b"").decode()   # why the generic kernel, if it is
+        # "unrolled" | "unrolled, general layout" | "unrolled, compiled at creation[ (from the cache)]" | "run-time loop" | "generic"
+        self.kernel_form = (lib().mpc_kernel_form(self._h) or b"").decode()
 
     def result(self) -> Dict:
         """``VPCResult`` (reference ``VPC.h:36-76``) derived from the integer vector."""

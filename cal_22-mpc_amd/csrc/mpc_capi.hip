@@ -31,6 +31,8 @@ constexpr size_t kRouteWords = MPC_TESTING ? 16 : 0;
 
 typedef unsigned long long u64;
 
+#include "mpc_jit.h"
+
 extern "C" {
 hipError_t mpc_launch_vpc_generic(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
 hipError_t mpc_launch_bdi(const void *, u64, int, uint16_t *, int8_t *, u64 *, int, hipStream_t);
@@ -39,6 +41,8 @@ hipError_t mpc_launch_bpc(const void *, u64, int, uint16_t *, int8_t *, u64 *, i
 hipError_t mpc_launch_synth(void *, u64, unsigned, int, u64, u64, const uint32_t *, hipStream_t);
 hipError_t mpc_launch_read_probe(const void *, u64, uint32_t *, int, hipStream_t);
 hipError_t mpc_launch_vpc_lane(const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int, hipStream_t);
+hipError_t mpc_launch_vpc_lane_jit(hipFunction_t, hipFunction_t, const void *, u64, const MpcVpcParams *, uint16_t *, int8_t *, u64 *, int,
+                                   hipStream_t);
 size_t mpc_vpc_lane_smem(const MpcVpcParams *);
 int mpc_vpc_lane_unrolled(const MpcVpcParams *);
 size_t mpc_vpc_generic_smem(const MpcVpcParams *);
@@ -88,6 +92,7 @@ struct mpc_handle {
   // device-visible buffer the kernel reads the lines from and writes the results to directly --
   // no staging copies, no 64 MiB slots; a call is one launch and one stream synchronisation
   uint8_t *mini = nullptr;       // [kMiniLines * L] lines | [kMiniLines] uint16 sizes | [kMiniLines] int8 clusters
+  mpcjit::Kernels jit;           // VPC: the unrolled kernels of a sequence without a built-in instantiation (mpc_jit.h)
   std::string error;
 };
 
@@ -176,8 +181,18 @@ int create_vpc_from_text(const std::string &text, int device, mpc_handle **out)
   if (rc == MPC_OK) {
     h->plan.params.tab = h->d_tab;
     h->plan.params.gtab = h->d_gtab;
+    // a module sequence without a built-in unrolled instantiation: compile it now (mpc_jit.h); when that is not
+    // possible the run-time module loop takes the configuration, and says so
+    if (mpcjit::eligible(h->plan.params, h->plan.fast)) {
+      std::string why;
+      (void)hipSetDevice(h->device);
+      if (!mpcjit::build(h->plan.params, MPC_TESTING, h->jit, why))
+        std::fprintf(stderr, "libmpc_hip: module sequence [%s] runs the run-time module loop (several times slower): %s\n",
+                     mpcjit::kinds_of(h->plan.params).c_str(), why.c_str());
+    }
     // the statistics accumulators of a workgroup live in LDS
-    const size_t smem = h->plan.fast ? mpc_vpc_lane_smem(&h->plan.params) : mpc_vpc_generic_smem(&h->plan.params);
+    const size_t smem = h->jit.mod ? mpc_vpc_lane_ring_plan(&h->plan.params, nullptr)
+                        : h->plan.fast ? mpc_vpc_lane_smem(&h->plan.params) : mpc_vpc_generic_smem(&h->plan.params);
     if (smem > 160 * 1024) {
       g_create_error = "histogram does not fit the 160 KiB LDS (too many clusters x bins)";
       rc = MPC_E_INVAL;
@@ -274,6 +289,9 @@ int launch(mpc_handle *h, const void *d_lines, u64 n, uint16_t *d_sizes, int8_t 
     e = mpc_launch_fpc(d_lines, n, h->L, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
   } else if (h->algorithm == 1) {
     e = mpc_launch_bdi(d_lines, n, h->L, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
+  } else if (h->jit.mod) {
+    e = mpc_launch_vpc_lane_jit(h->jit.stats, h->jit.lines, d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw,
+                                grid_for(h, n, 256, kWgPerCu), s);
   } else if (h->plan.fast) {
     e = mpc_launch_vpc_lane(d_lines, n, &h->plan.params, d_sizes, d_sel, h->d_raw, grid_for(h, n, 256, kWgPerCu), s);
   } else {
@@ -615,6 +633,7 @@ void mpc_destroy(mpc_handle *h)
     (void)hipStreamDestroy(h->stream);
   }
   if (h->mini) (void)hipHostFree(h->mini);
+  mpcjit::unload(h->jit);
   if (h->d_tab) (void)hipFree(h->d_tab);
   if (h->d_gtab) (void)hipFree(h->d_gtab);
   if (h->d_raw) (void)hipFree(h->d_raw);
@@ -638,6 +657,42 @@ int mpc_get_info(const mpc_handle *h, mpc_info *info)
 }
 
 const char *mpc_last_error(const mpc_handle *h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+// Needs no device: parses the configuration and, when its module sequence would be compiled at creation, runs that
+// compilation for gfx950 (nothing is loaded).  Returns the size of the code object, 0 when the sequence is built in or
+// takes the run-time loop, or a negative MPC_E_* with the compiler's log in `log`.
+long long mpc_jit_compile_check(const char *json_text, char *log, size_t cap)
+{
+  if (log && cap) log[0] = 0;
+  mpc::VpcConfig cfg;
+  std::string err;
+  int rc = mpc::parse_vpc_config(json_text ? json_text : "", cfg, err);
+  if (rc == 0) {
+    mpc::VpcPlan plan;
+    mpc::build_vpc_plan(cfg, plan);
+    if (!mpcjit::eligible(plan.params, plan.fast)) return 0;
+    unsigned ring_cfg = 0;
+    const size_t smem = mpc_vpc_lane_ring_plan(&plan.params, &ring_cfg);
+    std::string code;
+    if (mpcjit::compile(mpcjit::source_of(plan.params, smem, MPC_TESTING), "gfx950", mpcjit::source_dir(), code, err)) return (long long)code.size();
+    rc = MPC_E_HIP;
+  }
+  if (log && cap) {
+    std::strncpy(log, err.c_str(), cap - 1);
+    log[cap - 1] = 0;
+  }
+  return rc;
+}
+
+const char *mpc_kernel_form(const mpc_handle *h)
+{
+  if (!h) return "";
+  if (h->algorithm != 0) return "unrolled";
+  if (!h->plan.fast) return "generic";
+  if (h->jit.mod) return h->jit.from_cache ? "unrolled, compiled at creation (from the cache)" : "unrolled, compiled at creation";
+  if (!mpc_vpc_lane_unrolled(&h->plan.params)) return "run-time loop";
+  return h->plan.params.gen_layout ? "unrolled, general layout" : "unrolled";
+}
 
 const char *mpc_path_reason(const mpc_handle *h)
 {
@@ -965,8 +1020,10 @@ int mpc_config_describe(const char *json_text, char *out, size_t cap)
         ", \"has_aws\": " + (cfg.has_aws ? "true" : "false") + ", \"hist_bins\": " + std::to_string(cfg.hist_bins) + ", \"enc_bits\": [";
     for (size_t i = 0; i < cfg.enc_bits.size(); i++) s += (i ? ", " : "") + std::to_string(cfg.enc_bits[i]);
     s += "], \"path\": \"" + std::string(plan.fast ? "fast" : "generic") + "\", \"why_generic\": \"" + plan.why_generic +
-         "\", \"sequence\": \"" + std::string(!plan.fast ? "" : (mpc_vpc_lane_unrolled(&plan.params) ? "unrolled" : "run-time loop")) +
-         "\", \"general_layout\": \"" + std::string(plan.fast && mpc_vpc_lane_unrolled(&plan.params) && plan.params.gen_layout ? "yes" : "no") +
+         "\", \"sequence\": \"" + std::string(!plan.fast ? "" : (mpc_vpc_lane_unrolled(&plan.params) || mpcjit::eligible(plan.params, plan.fast) ? "unrolled" : "run-time loop")) +
+         "\", \"compiled\": \"" + std::string(!plan.fast ? "" : mpc_vpc_lane_unrolled(&plan.params) ? "built in" :
+                                            mpcjit::eligible(plan.params, plan.fast) ? "at creation" : "") +
+         "\", \"general_layout\": \"" + std::string(plan.fast && plan.params.gen_layout && (mpc_vpc_lane_unrolled(&plan.params) || mpcjit::eligible(plan.params, plan.fast)) ? "yes" : "no") +
          "\", \"scan_order\": \"" + std::string(!plan.fast ? "" : (plan.params.byte_major ? "byte-major" : "plane-major")) +
          "\", \"modules\": [";
     for (int i = 0; i < cfg.M; i++) {

@@ -3,7 +3,19 @@
 // arguments.
 #pragma once
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#else      /* hiprtc (mpc_jit.h): no <stdint.h>; the fixed-width names the kernels use */
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long uintptr_t;
+#endif
 
 #define MPC_MAX_MODULES 32        /* M (AllZero + AllWordSame + prediction modules) */
 #define MPC_MAX_PRED    31        /* prediction (PredComp) modules */

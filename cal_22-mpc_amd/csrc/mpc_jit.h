@@ -1,0 +1,280 @@
+// mpc_jit.h -- run-time compilation of the unrolled lane kernel for ONE more module sequence (host side, used by
+// mpc_capi.hip when a handle is created).
+//
+// The library ships the unrolled kernels for 13 module sequences (mpc_vpc_lane.hip, MPC_LANE_SEQUENCES); any other
+// sequence of OneBase / ConsecutiveBase / DiffBase / WeightBase modules used to fall back to the run-time module loop
+// at about 0.3 of the HBM peak.  The group code is a template over the sequence, so the missing
+// instantiation is compiled when the configuration is loaded: hiprtc (the ROCm run-time compiler, loaded with dlopen:
+// the library does not depend on it) compiles mpc_vpc_lane.hip -- the very source the built-in kernels come from, read
+// from the csrc/ directory next to the library -- with the sequence as template arguments, the code object is loaded
+// with hipModuleLoadData and kept in the handle; a copy goes to a cache directory keyed by a hash of the sources, the
+// options and the compiler version, so that the next process skips the compilation (about 3 s).  Nothing here is a
+// fallback path of the product: when hiprtc, the sources or the compilation are not available, the configuration runs
+// the run-time module loop as before and a line on stderr says why.
+//
+//   MPC_JIT=0            never compile at run time
+//   MPC_JIT_SRC=DIR      the kernel sources (default: <directory of libmpc_hip*.so>/csrc)
+//   MPC_JIT_CACHE=DIR    code object cache (default: $XDG_CACHE_HOME/mpc_hip or ~/.cache/mpc_hip); "" = no cache
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "mpc_device.h"
+
+extern "C" size_t mpc_vpc_lane_ring_plan(const MpcVpcParams *P, unsigned *ring_cfg);
+extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P);
+
+namespace mpcjit {
+
+constexpr int kMaxModules = 8;      // longer sequences stay on the run-time loop (code size, compile time)
+
+struct Kernels {
+  hipModule_t mod = nullptr;
+  hipFunction_t stats = nullptr;    // statistics only
+  hipFunction_t lines = nullptr;    // + per-line outputs
+  bool from_cache = false;
+};
+
+inline void unload(Kernels &k)
+{
+  if (k.mod) (void)hipModuleUnload(k.mod);
+  k = Kernels();
+}
+
+// the sequence as the kernels' template arguments (lane-kernel kinds: MPC_FK_* | 8 / 16 for periodic tables)
+inline std::string kinds_of(const MpcVpcParams &P)
+{
+  std::string s;
+  for (int q = 0; q < P.n_pred; q++) {
+    const MpcFastModule &f = P.fm[q];
+    const int kind = f.kind | (f.prev_word == 1 ? 8 : (f.prev_word == 2 ? 16 : 0));
+    s += (q ? ", " : "") + std::to_string(kind);
+  }
+  return s;
+}
+
+// a fast-path configuration whose sequence has no built-in instantiation but could have one
+inline bool eligible(const MpcVpcParams &P, bool fast)
+{
+  const char *env = std::getenv("MPC_JIT");
+  if (env && std::strcmp(env, "0") == 0) return false;
+  if (!fast || P.runtime_only || P.n_pred < 1 || P.n_pred > kMaxModules) return false;
+  if (!(P.L == 32 || P.L == 64 || P.L == 128)) return false;
+  if (mpc_vpc_lane_unrolled(&P)) return false;            // built in
+  unsigned ring_cfg = 0;
+  return mpc_vpc_lane_ring_plan(&P, &ring_cfg) != 0;       // the rings fit beside the histogram
+}
+
+namespace detail {
+
+inline std::string dir_of_this_library()
+{
+  Dl_info info;
+  if (!dladdr(reinterpret_cast<const void *>(&mpc_vpc_lane_ring_plan), &info) || !info.dli_fname) return "";
+  std::string p = info.dli_fname;
+  const size_t slash = p.rfind('/');
+  return slash == std::string::npos ? "." : p.substr(0, slash);
+}
+
+inline bool read_file(const std::string &path, std::string &out)
+{
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  out = ss.str();
+  return true;
+}
+
+inline unsigned long long fnv1a(const std::string &s, unsigned long long h = 1469598103934665603ull)
+{
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+inline std::string cache_dir()
+{
+  const char *e = std::getenv("MPC_JIT_CACHE");
+  if (e) return e;                                         // ("" switches the cache off)
+  const char *x = std::getenv("XDG_CACHE_HOME");
+  if (x && *x) return std::string(x) + "/mpc_hip";
+  const char *h = std::getenv("HOME");
+  if (h && *h) return std::string(h) + "/.cache/mpc_hip";
+  return "";
+}
+
+inline void mkdirs(const std::string &dir)
+{
+  for (size_t i = 1; i <= dir.size(); i++)
+    if (i == dir.size() || dir[i] == '/') (void)::mkdir(dir.substr(0, i).c_str(), 0755);
+}
+
+struct Rtc {
+  void *lib = nullptr;
+  decltype(&hiprtcCreateProgram) create = nullptr;
+  decltype(&hiprtcCompileProgram) compile = nullptr;
+  decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+  decltype(&hiprtcGetProgramLog) log = nullptr;
+  decltype(&hiprtcGetCodeSize) code_size = nullptr;
+  decltype(&hiprtcGetCode) code = nullptr;
+  decltype(&hiprtcDestroyProgram) destroy = nullptr;
+  decltype(&hiprtcVersion) version = nullptr;
+  bool ok() const { return create && compile && log_size && log && code_size && code && destroy; }
+};
+
+inline Rtc &rtc()
+{
+  static Rtc r = []() {
+    Rtc t;
+    for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+      t.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (t.lib) break;
+    }
+    if (!t.lib) return t;
+#define MPC_RTC_SYM(field, sym) t.field = reinterpret_cast<decltype(t.field)>(dlsym(t.lib, #sym))
+    MPC_RTC_SYM(create, hiprtcCreateProgram);
+    MPC_RTC_SYM(compile, hiprtcCompileProgram);
+    MPC_RTC_SYM(log_size, hiprtcGetProgramLogSize);
+    MPC_RTC_SYM(log, hiprtcGetProgramLog);
+    MPC_RTC_SYM(code_size, hiprtcGetCodeSize);
+    MPC_RTC_SYM(code, hiprtcGetCode);
+    MPC_RTC_SYM(destroy, hiprtcDestroyProgram);
+    MPC_RTC_SYM(version, hiprtcVersion);
+#undef MPC_RTC_SYM
+    return t;
+  }();
+  return r;
+}
+
+}  // namespace detail
+
+// the translation unit handed to hiprtc: the lane kernel's device code and two kernels of the sequence
+inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testing)
+{
+  const int W = P.L / 4;
+  const std::string targs = std::to_string(W) + ", OUT_, " + (P.gen_layout ? "true" : "false") + ", " + kinds_of(P);
+  std::ostringstream s;
+  s << "#define MPC_LANE_JIT 1\n"
+    << "#define MPC_TESTING " << testing << "\n"
+    << "#include \"mpc_vpc_lane.hip\"\n"
+    << "#define MPC_JIT_KERNEL(NAME, OUT_) \\\n"
+    << "extern \"C\" __global__ void MPC_LANE_BOUNDS(" << W << ", " << P.n_pred << ") \\\n"
+    << "NAME(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P, uint16_t *__restrict__ sizes_out, \\\n"
+    << "     int8_t *__restrict__ sel_out, u64 *gstats, u32 ring_cfg) \\\n"
+    << "{ \\\n"
+    << "  /* the launch's LDS as ONE static array (it sits at LDS address 0, where the ring code expects it) */ \\\n"
+    << "  __shared__ __attribute__((aligned(1024))) unsigned char smem[" << smem_bytes << "]; \\\n"
+    << "  if ((u32)(uintptr_t)smem != 0u) __builtin_trap(); \\\n"
+    << "  vpc_lane_body<" << targs << ">(smem, lines, n_lines, first_line, P, sizes_out, sel_out, gstats, ring_cfg); \\\n"
+    << "}\n"
+    << "MPC_JIT_KERNEL(mpc_jit_stats, false)\n"
+    << "MPC_JIT_KERNEL(mpc_jit_lines, true)\n";
+  return s.str();
+}
+
+inline std::string source_dir()
+{
+  const char *src_env = std::getenv("MPC_JIT_SRC");
+  return src_env ? std::string(src_env) : detail::dir_of_this_library() + "/csrc";
+}
+
+// hiprtc: the sequence's translation unit -> a gfx950 code object.  Needs no device (`arch` names the target), which
+// is how the CPU test suite checks that the kernel source still compiles this way (mpc_jit_compile_check).
+inline bool compile(const std::string &source, const std::string &arch, const std::string &src_dir, std::string &code, std::string &why)
+{
+  detail::Rtc &rtc = detail::rtc();
+  if (!rtc.ok()) { why = "libhiprtc.so could not be loaded"; return false; }
+  hiprtcProgram prog = nullptr;
+  if (rtc.create(&prog, source.c_str(), "mpc_jit_sequence.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { why = "hiprtcCreateProgram failed"; return false; }
+  const std::string o_arch = "--offload-arch=" + arch, o_inc = "-I" + src_dir;
+  const char *copts[] = {o_arch.c_str(), "-O3", "-std=c++17", o_inc.c_str()};
+  const hiprtcResult r = rtc.compile(prog, 4, copts);
+  if (r != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    (void)rtc.log_size(prog, &n);
+    std::string log(n, '\0');
+    if (n) (void)rtc.log(prog, &log[0]);
+    why = "hiprtc compilation failed: " + log.substr(0, 1500);
+    (void)rtc.destroy(&prog);
+    return false;
+  }
+  size_t n = 0;
+  (void)rtc.code_size(prog, &n);
+  code.resize(n);
+  (void)rtc.code(prog, &code[0]);
+  (void)rtc.destroy(&prog);
+  return true;
+}
+
+// Compile (or take from the cache) and load the two kernels of P's sequence on the current device.
+// Returns false with a reason in `why`; the caller then runs the run-time module loop.
+inline bool build(const MpcVpcParams &P, int testing, Kernels &out, std::string &why)
+{
+  unsigned ring_cfg = 0;
+  const size_t smem = mpc_vpc_lane_ring_plan(&P, &ring_cfg);
+  if (smem == 0) { why = "the line rings do not fit the LDS beside the histogram"; return false; }
+  const std::string src_dir = source_dir();
+  std::string all_sources;
+  for (const char *f : {"mpc_vpc_lane.hip", "mpc_kernel_common.h", "mpc_ring.h", "mpc_device.h"}) {
+    std::string text;
+    if (!detail::read_file(src_dir + "/" + f, text)) { why = "kernel source " + src_dir + "/" + f + " not found"; return false; }
+    all_sources += text;
+  }
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { why = "no device"; return false; }
+  const std::string arch = prop.gcnArchName;
+  if (arch.compare(0, 6, "gfx950") != 0) { why = "device is " + arch + ", the kernels are written for gfx950"; return false; }
+  const std::string source = source_of(P, smem, testing);
+
+  // ---- cache: keyed by everything the code object depends on ----
+  int vmaj = 0, vmin = 0;
+  if (detail::rtc().version) (void)detail::rtc().version(&vmaj, &vmin);
+  char key[32];
+  std::snprintf(key, sizeof key, "%016llx", detail::fnv1a(source + all_sources + "|" + arch + "|" + std::to_string(vmaj) + "." + std::to_string(vmin)));
+  const std::string cdir = detail::cache_dir();
+  const std::string cpath = cdir.empty() ? "" : cdir + "/lane_" + key + ".hsaco";
+  auto load = [&](const std::string &code) -> hipError_t {
+    hipError_t e = hipModuleLoadData(&out.mod, code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&out.stats, out.mod, "mpc_jit_stats");
+    if (e == hipSuccess) e = hipModuleGetFunction(&out.lines, out.mod, "mpc_jit_lines");
+    if (e != hipSuccess) unload(out);
+    return e;
+  };
+  std::string code;
+  if (!cpath.empty() && detail::read_file(cpath, code) && !code.empty()) {
+    if (load(code) == hipSuccess) {
+      out.from_cache = true;
+      return true;
+    }
+    (void)std::remove(cpath.c_str());      // a stale or damaged cache entry: compile again
+  }
+  if (!compile(source, arch, src_dir, code, why)) return false;
+  const hipError_t e = load(code);
+  if (e != hipSuccess) { why = std::string("loading the compiled kernels failed: ") + hipGetErrorString(e); return false; }
+  if (!cpath.empty()) {
+    // written under a private name and renamed: another process may be doing the same
+    detail::mkdirs(cdir);
+    const std::string tmp = cpath + "." + std::to_string((long)getpid());
+    std::ofstream f(tmp, std::ios::binary);
+    if (f) {
+      f.write(code.data(), (std::streamsize)code.size());
+      f.close();
+      if (!f || std::rename(tmp.c_str(), cpath.c_str()) != 0) (void)std::remove(tmp.c_str());
+    }
+  }
+  return true;
+}
+
+}  // namespace mpcjit

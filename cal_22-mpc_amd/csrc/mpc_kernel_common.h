@@ -1,8 +1,10 @@
 // mpc_kernel_common.h -- device helpers shared by the gfx950 kernels: SWAR byte arithmetic
 // on 32-bit words, the common encoder's row classification, per-workgroup LDS statistics.
 #pragma once
+#ifndef __HIPCC_RTC__      /* (hiprtc, mpc_jit.h: the runtime's declarations and the fixed-width types are built in) */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "mpc_device.h"
 

@@ -1067,11 +1067,13 @@ static LaneLds lane_lds_plan(const MpcVpcParams *P, int wpb, bool wants_queue)
 // ring_cfg: ring stages per wave (bits 0..7) | queue entries per wave << 8 (lane_lds_plan; the run-time loop ignores it)
 // GEN: the general-layout twin (vpc_lane_gen_kernel): RootIndex 0..15 per module, scan tables that stop after a whole
 // number of bit planes.  The plain kernels keep their code (and their names in the profiles) untouched.
+// smem: the launch's LDS (the built-in kernels: the dynamic allocation; a run-time compiled one: a static array of the
+// plan's size, so that its launch through the module API needs no function attribute)
 template <int W, bool OUT, bool GEN, int... KINDS>
-__device__ __forceinline__ void vpc_lane_body(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, const MpcVpcParams &P,
-                                              uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats, u32 ring_cfg)
+__device__ __forceinline__ void vpc_lane_body(unsigned char *smem, const uint4 *__restrict__ lines, u32 n_lines, u64 first_line,
+                                              const MpcVpcParams &P, uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out,
+                                              u64 *gstats, u32 ring_cfg)
 {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NQ = W / 4;             // 16-byte pieces per line
   constexpr u32 WPB = lane_wpb<W, sizeof...(KINDS)>();       // waves per workgroup
   LaneEnv E;
@@ -1265,16 +1267,21 @@ __global__ void MPC_LANE_BOUNDS(W, (sizeof...(KINDS)))
 vpc_lane_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
                 uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats, u32 ring_cfg)
 {
-  vpc_lane_body<W, OUT, false, KINDS...>(lines, n_lines, first_line, P, sizes_out, sel_out, gstats, ring_cfg);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  vpc_lane_body<W, OUT, false, KINDS...>(smem, lines, n_lines, first_line, P, sizes_out, sel_out, gstats, ring_cfg);
 }
 template <int W, bool OUT, int... KINDS>
 __global__ void MPC_LANE_BOUNDS(W, (sizeof...(KINDS)))
 vpc_lane_gen_kernel(const uint4 *__restrict__ lines, u32 n_lines, u64 first_line, MpcVpcParams P,
                     uint16_t *__restrict__ sizes_out, int8_t *__restrict__ sel_out, u64 *gstats, u32 ring_cfg)
 {
-  vpc_lane_body<W, OUT, true, KINDS...>(lines, n_lines, first_line, P, sizes_out, sel_out, gstats, ring_cfg);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  vpc_lane_body<W, OUT, true, KINDS...>(smem, lines, n_lines, first_line, P, sizes_out, sel_out, gstats, ring_cfg);
 }
 
+// Everything below is host code: launchers of the built-in instantiations.  A run-time compilation of one more sequence
+// (mpc_jit.h: hiprtc, -DMPC_LANE_JIT) takes the device code above only and adds its own two kernels.
+#ifndef MPC_LANE_JIT
 #define OB MPC_FK_ONEBASE
 #define CS MPC_FK_CONSEC
 #define DF MPC_FK_DIFF
@@ -1391,7 +1398,9 @@ static bool lane_has_line_size(int L)
 #endif
 }
 
+#endif   // !MPC_LANE_JIT
 }  // namespace
+#ifndef MPC_LANE_JIT
 
 // Build layout.  Compiled as it is, this file holds every line size (development builds).  The product build
 // (cal_22-mpc_amd/build.py) compiles it four times in parallel: -DMPC_LANE_W=8 / 16 / 32 give the kernels of one
@@ -1409,6 +1418,43 @@ extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P)
   MPC_LANE_SEQUENCES(X)
 #undef X
   return 0;
+}
+
+// LDS plan of an unrolled launch, whether or not the sequence is built in: bytes (0: the rings do not fit beside the
+// histogram) and the kernels' ring_cfg argument.  (mpc_jit.h: the size of a run-time compiled kernel's static LDS array.)
+extern "C" size_t mpc_vpc_lane_ring_plan(const MpcVpcParams *P, unsigned *ring_cfg)
+{
+  const LaneLds plan = lane_lds_plan(P, lane_wpb_of(P->L), P->L <= 64);
+  if (ring_cfg) *ring_cfg = plan.stages | (plan.cap << 8);
+  return plan.stages == 0 ? 0 : plan.bytes;
+}
+
+// Launch of a run-time compiled sequence (mpc_jit.h): the grid and the kernel arguments of lane_launch, through the
+// module API; the kernels carry their LDS as a static array.
+extern "C" hipError_t mpc_launch_vpc_lane_jit(hipFunction_t fn_stats, hipFunction_t fn_lines, const void *d_lines, u64 n_lines,
+                                              const MpcVpcParams *P, uint16_t *d_sizes, int8_t *d_sel, u64 *d_stats, int grid,
+                                              hipStream_t stream)
+{
+  unsigned ring_cfg = 0;
+  if (mpc_vpc_lane_ring_plan(P, &ring_cfg) == 0) return hipErrorInvalidConfiguration;
+  const int wpb = lane_wpb_of(P->L);
+  const u64 max_lines = 1ull << 30;     // 32-bit line indices inside the kernel
+  hipFunction_t fn = (d_sizes || d_sel) ? fn_lines : fn_stats;
+  for (u64 done = 0; done < n_lines; done += max_lines) {
+    const u64 take = (n_lines - done) < max_lines ? (n_lines - done) : max_lines;
+    const uint4 *l = static_cast<const uint4 *>(d_lines) + done * (u64)(P->L / 16);
+    u32 n32 = (u32)take;
+    u64 first_line = done;
+    const u64 want = (take / 64u + (u64)wpb - 1u) / (u64)wpb;
+    const u64 cap = (u64)grid / (wpb == 16 ? 16u : 8u);
+    int wgrid = (int)(want < cap ? want : cap);
+    if (wgrid < 1) wgrid = 1;
+    MpcVpcParams params = *P;
+    void *args[] = {&l, &n32, &first_line, &params, &d_sizes, &d_sel, &d_stats, &ring_cfg};
+    const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)wgrid, 1, 1, 64u * (unsigned)wpb, 1, 1, 0, stream, args, nullptr);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 // dynamic LDS of a launch (the host checks it against the 160 KiB of a CU when a handle is created)
@@ -1467,3 +1513,4 @@ extern "C" hipError_t MPC_LAUNCH_NAME(const void *d_lines, u64 n_lines, const Mp
   return hipSuccess;
 }
 #endif
+#endif   // !MPC_LANE_JIT

@@ -88,6 +88,16 @@ int mpc_get_info(const mpc_handle *h, mpc_info *info);
  * than the fast kernel): one sentence naming the module and the property; "" for every other handle.  The
  * `compressor` CLI prints it to stderr so that the slow path is never entered silently.                          */
 const char *mpc_path_reason(const mpc_handle *h);
+/* The form of the kernel the handle launches, for logs and tests: "unrolled" (a built-in instantiation of the module
+ * sequence), "unrolled, general layout" (RootIndex 1..15 / whole-plane truncation), "unrolled, compiled at creation"
+ * (the sequence had no built-in instantiation: hiprtc compiled it when the handle was created; "(from the cache)"
+ * when a previous process had), "run-time loop", "generic".  No counterpart in the reference.                          */
+const char *mpc_kernel_form(const mpc_handle *h);
+/* Build check, needs no device: when the configuration's module sequence has no built-in unrolled instantiation and would
+ * be compiled when a handle is created (hiprtc), compile it now for gfx950 and return the size of the
+ * code object; 0 when nothing would be compiled (built in, or a layout that takes the run-time loop); negative MPC_E_*
+ * with the parser's or the compiler's message in `log`.                                                             */
+long long mpc_jit_compile_check(const char *config_json_text, char *log, size_t log_cap);
 /* Last error text of this handle (or of the last failed create if h==NULL). */
 const char *mpc_last_error(const mpc_handle *h);
 

@@ -212,3 +212,28 @@ def test_short_scan_tables_pin_the_scan_order(mpc, configs):
     d = mpc.describe_config(configs.make_config(L, [{"name": "AllZero"}, configs.one_base(L, 0, True, bm), configs.one_base(L, 0, False, pm)]))
     assert d["path"] == "generic"
     assert mpc.describe_config(configs.probe_config(L))["scan_order"] == "plane-major"
+
+
+def test_run_time_compilation_of_a_module_sequence_builds_for_gfx950(mpc, configs):
+    """A module sequence without a built-in unrolled instantiation is compiled with hiprtc when a handle is created
+    (csrc/mpc_jit.h).  The compilation itself needs no device: the same source the library would hand to hiprtc on a GPU
+    box is compiled here for gfx950 (nothing is loaded), at every line size, with and without the general layout."""
+    az, aws = {"name": "AllZero"}, {"name": "AllWordSame"}
+    for L in (32, 64, 128):
+        prev1 = [max(i - 1, 0) for i in range(L)]
+        prev4 = [max(i - 4, 0) for i in range(L)]
+        w2 = [[1.0, 0.5][i % 2] for i in range(L)]
+        w3 = [[2.0, 0.25][i % 2] for i in range(L)]                 # two shifted classes (the WEIGHT2 form)
+        seqs = [[az, aws, configs.one_base(L, 0, True), configs.diff_base(L, prev1, [3] * L, 0, False), configs.weight_base(L, prev4, w2, 0, True),
+                 configs.one_base(L, 0, False)],
+                [az, configs.consecutive_base(L, 0, True), configs.weight_base(L, prev4, w3, 2, False), configs.one_base(L, 9, True)]]
+        for mods in seqs:
+            cfg = configs.make_config(L, mods)
+            d = mpc.describe_config(cfg)
+            assert d["path"] == "fast" and d["sequence"] == "unrolled" and d["compiled"] == "at creation", d
+            assert mpc.jit_compile_check(cfg) > 10000
+    # built in / run-time loop: nothing to compile
+    assert mpc.describe_config(configs.probe_config(64))["compiled"] == "built in"
+    assert mpc.jit_compile_check(configs.probe_config(64)) == 0
+    cfg = configs.make_config(64, [az, configs.one_base(64, root=40), configs.consecutive_base(64, 0, True)])
+    assert mpc.describe_config(cfg)["sequence"] == "run-time loop" and mpc.jit_compile_check(cfg) == 0

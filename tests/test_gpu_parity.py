@@ -313,6 +313,74 @@ def test_vpc_general_layout_twins(mpc, oracle, configs, traces, L):
     check(probe((0, 0, 0), 16), False, 3000)
 
 
+@pytest.mark.parametrize("L", [32, 64, 128])
+def test_vpc_sequences_compiled_at_creation(mpc, oracle, configs, traces, L, tmp_path, monkeypatch):
+    """A module sequence without a built-in unrolled instantiation gets one when the handle is created: hiprtc compiles the
+    lane kernel's own source with the sequence as template arguments (csrc/mpc_jit.h; round 2 ran such sequences on the
+    run-time loop at 0.3 of the peak).  Results against the oracle with per-line outputs and in statistics-only mode; the
+    handle says which form it launches; the code object is cached (second handle: from the cache); MPC_JIT=0 keeps the
+    run-time loop, with the same results."""
+    monkeypatch.setenv("MPC_JIT_CACHE", str(tmp_path / "jit"))
+    monkeypatch.delenv("MPC_JIT", raising=False)
+    rng = np.random.default_rng(500 + L)
+    lines = np.concatenate([traces.structured(4000, L, seed=29), traces.mixed(2500, L), traces.random_u32(600, L),
+                            traces.sine_f32(1024, L), traces.counters_u32(400, L), traces.zeros(70, L), traces.word_same(70, L)])
+    lines = lines[rng.permutation(len(lines))]
+    az, aws = {"name": "AllZero"}, {"name": "AllWordSame"}
+
+    def trunc(ts):
+        return None if ts is None else {"TableSize": ts, "Rows": [i // L for i in range(ts)], "Cols": [i % L for i in range(ts)]}
+    prev1 = [max(i - 1, 0) for i in range(L)]
+    prev4 = [max(i - 4, 0) for i in range(L)]
+    prev8 = [max(i - 8, 0) for i in range(L)]
+    diff = [(-2 + (i % 5)) for i in range(L)]
+    w2 = [[1.0, 0.5][i % 2] for i in range(L)]
+    w3 = [[2.0, 0.25][i % 2] for i in range(L)]              # two shifted classes
+    seqs = {
+        "OB DF WT OB": lambda s, r: [az, aws, configs.one_base(L, r[0], True, s), configs.diff_base(L, prev1, diff, r[1], False, s),
+                                     configs.weight_base(L, prev4, w2, r[2], True, s), configs.one_base(L, 0, False, s)],
+        "CS WT2 OB": lambda s, r: [az, configs.consecutive_base(L, 0, True, s), configs.weight_base(L, prev4, w3, r[1], False, s),
+                                   configs.one_base(L, r[0], True, s)],
+        "8 modules": lambda s, r: [az, aws, configs.diff_base(L, prev8, [1] * L, r[1], True, s), configs.one_base(L, r[0], False, s),
+                                   configs.consecutive_base(L, 0, False, s), configs.weight_base(L, prev8, w2, r[2], True, s),
+                                   configs.diff_base(L, prev4, diff, 0, False, s), configs.weight_base(L, prev1, w2, 0, False, s),
+                                   configs.one_base(L, 0, True, s), configs.consecutive_base(L, 0, True, s)],
+    }
+
+    def run(cfg, form_prefix):
+        ev = mpc.VPC(cfg)
+        assert ev.kernel_path == mpc.MPC_PATH_VPC_FAST and ev.kernel_form.startswith(form_prefix), ev.kernel_form
+        o = oracle.VpcOracle(cfg)
+        s_ref, k_ref = o.compress(lines)
+        s, k = ev.compress_lines(lines)
+        assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all()
+        ev.reset()
+        ev.compress_lines(lines, want_sizes=False, want_selected=False)
+        assert (ev.stats_vector() == o.stats_vector()).all()
+        form = ev.kernel_form
+        ev.close()
+        return form
+
+    for name, make in seqs.items():
+        for ts, roots in ((None, (0, 0, 0)), (6 * L, (5, 3, 2))):          # plain layout, general layout
+            cfg = configs.make_config(L, make(trunc(ts), roots))
+            if L == 128 and name == "8 modules":
+                # 11 clusters x 1030 bins: the histogram leaves no room for the line rings, nothing is compiled
+                assert mpc.describe_config(cfg)["sequence"] == "run-time loop"
+                run(cfg, "run-time loop")
+                continue
+            d = mpc.describe_config(cfg)
+            assert d["sequence"] == "unrolled" and d["compiled"] == "at creation" and d["general_layout"] == ("yes" if ts else "no"), (name, d)
+            first = run(cfg, "unrolled, compiled at creation")
+            assert "cache" not in first, (name, first)
+            assert run(cfg, "unrolled, compiled at creation") == "unrolled, compiled at creation (from the cache)"
+    # switched off: the run-time module loop, same results
+    monkeypatch.setenv("MPC_JIT", "0")
+    cfg = configs.make_config(L, seqs["OB DF WT OB"](None, (0, 0, 0)))
+    assert mpc.describe_config(cfg)["sequence"] == "run-time loop"
+    assert run(cfg, "run-time loop") == "run-time loop"
+
+
 def test_vpc_many_modules_large_histogram(mpc, oracle, configs, traces):
     """16 modules at 128-byte lines: 17 clusters x 1030 bins = 70 KB of LDS histogram, more than a
     kernel's default 64 KiB (fast kernel with the run-time module loop, and the generic kernel)."""

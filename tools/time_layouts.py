@@ -35,5 +35,5 @@ for wl in ("random_u32", "mixed"):
         b.record(st); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 3
         d = mpc.describe_config(cfg)
-        print(f"{wl:11s} {name:32s} path {d['path']:7s} {d['sequence']:13s} {m * L / ms / 1e6:8.0f} GB/s  {m * L / ms / 1e6 / 8000:.3f} of peak")
+        print(f"{wl:11s} {name:32s} path {d['path']:7s} {d['sequence']:13s} {d.get('compiled', ''):11s} {m * L / ms / 1e6:8.0f} GB/s  {m * L / ms / 1e6 / 8000:.3f} of peak")
         ev.close()
