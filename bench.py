@@ -214,6 +214,52 @@ def time_workload(torch, mpc, configs, buf, stream, device, workload, algo, byte
     return rec
 
 
+def layout_configs(configs, L=64):
+    """VPC configurations beyond the probe's layout: non-zero RootIndex, a scan table that stops
+    after 6 of the 8 bit planes, a module sequence without a built-in kernel (compiled when the handle is created)."""
+    az, aws = {"name": "AllZero"}, {"name": "AllWordSame"}
+    prev1 = [max(i - 1, 0) for i in range(L)]
+    prev4 = [max(i - 4, 0) for i in range(L)]
+    w2 = [[1.0, 0.5][i % 2] for i in range(L)]
+    d1 = [1 if i % 4 == 0 else 0 for i in range(L)]
+    t6 = {"TableSize": 6 * L, "Rows": [i // L for i in range(6 * L)], "Cols": [i % L for i in range(6 * L)]}
+    return [
+        ("probe modules, RootIndex 5/0/3/2", configs.make_config(L, [az, aws, configs.one_base(L, 5, True), configs.consecutive_base(L, 0, True),
+                                                                     configs.diff_base(L, prev4, d1, 3, False), configs.weight_base(L, prev4, w2, 2, True)])),
+        ("probe modules, TableSize 6 L", configs.make_config(L, [az, aws, configs.one_base(L, 0, True, t6), configs.consecutive_base(L, 0, True, t6),
+                                                                 configs.diff_base(L, prev4, d1, 0, False, t6), configs.weight_base(L, prev4, w2, 0, True, t6)])),
+        ("OneBase, DiffBase(i-1), WeightBase(i-4), OneBase: no built-in kernel", configs.make_config(L, [
+            az, aws, configs.one_base(L, 0, True), configs.diff_base(L, prev1, [(-2 + (i % 5)) for i in range(L)], 0, False),
+            configs.weight_base(L, prev4, w2, 0, True), configs.one_base(L, 0, False)])),
+    ]
+
+
+def time_layout(torch, mpc, buf, stream, device, name, cfg, n, L, steps=6):
+    """One `layouts` record: random u32 lines (already in buf) through a VPC configuration of another layout."""
+    ev = mpc.VPC(cfg, device=device)
+    sp = stream.cuda_stream
+    for _ in range(4):
+        ev.compress_device(buf.data_ptr(), n, stream=sp)
+    torch.cuda.synchronize()
+    ev.reset()
+    ms = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        ev.compress_device(buf.data_ptr(), n, stream=sp)
+        b.record(stream)
+        torch.cuda.synchronize()
+        ms.append(a.elapsed_time(b))
+    v = ev.stats_vector()
+    assert int(v[0]) == n * steps, (name, int(v[0]), n * steps)
+    avg = sum(ms) / len(ms)
+    rec = {"config": name, "workload": "random_u32", "line_size": L, "blocks": n, "kernel_form": ev.kernel_form,
+           "kernel_ms_avg": avg, "kernel_ms_min": min(ms), "frac_of_hbm_peak": n * L / (avg / 1e3) / 1e9 / HBM_PEAK_GBPS,
+           "compression_ratio": float(v[1]) / float(v[2])}
+    ev.close()
+    return rec
+
+
 SUB_WORKLOADS = [("sine_f32", "VPC"), ("mixed", "VPC"), ("zeros", "VPC"), ("pointers_u64_128", "VPC"),
                  ("random_u32_32", "VPC"), ("mixed_32", "VPC"),
                  ("random_u32", "BDI"), ("sine_f32", "BDI"), ("mixed", "BDI"), ("pointers_u64_128", "BDI"), ("random_u32_32", "BDI"),
@@ -384,6 +430,12 @@ def main():
             if (wl, algo) == (args.workload, args.algo):
                 continue
             workloads.append(time_workload(torch, mpc, configs, buf, stream, local_rank, wl, algo, n * L, power=power))
+    # ... and the random-u32 trace through configurations of other layouts (general-layout twins, run-time compiled sequence)
+    layouts = None
+    if world == 1 and not args.no_workloads and args.workload == "random_u32" and L == 64:
+        mpc.synth_fill(buf.data_ptr(), n, L, kind, first_line=0)
+        torch.cuda.synchronize()
+        layouts = [time_layout(torch, mpc, buf, stream, local_rank, name, cfg, n, L) for name, cfg in layout_configs(configs, L)]
     # N > 1: BASELINE config 4 -- mixed int/fp blocks sharded contiguously over the ranks, one RCCL
     # all-reduce of the statistics per pass -- as its own sub-record next to the primary value (which
     # stays on the N = 1 workload so that the scaling curve is comparable).
@@ -471,6 +523,8 @@ def main():
                 w["roofline"]["traffic"], w["roofline"]["traffic_source"] = traffic_record(
                     tj, w["algorithm"], w["workload"], w["line_size"], w["blocks"])
             out["workloads"] = workloads
+        if layouts is not None:
+            out["layouts"] = layouts
         if world > 1:
             # what the collective of the timed steps ran on, at the top level of the line
             out["rccl_ranks"] = dist.get_world_size()
