@@ -16,6 +16,7 @@ HOST = os.path.join(HERE, "host")
 LIB = os.path.join(HERE, "libmpc_hip.so")
 TEST_LIB = os.path.join(HERE, "libmpc_hip_test.so")      # -DMPC_TESTING=1: route counters + MPC_TEST_GRID (tests only)
 CLI = os.path.join(ROOT, "bin", "compressor")
+JITC = os.path.join(HERE, "mpc_jitc")                   # the run-time compiler's helper process (csrc/mpc_jitc.cpp)
 
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 ARCH = "gfx950"
@@ -69,6 +70,20 @@ def build_lib(force: bool = False, verbose: bool = False, test: bool = False) ->
     return LIB
 
 
+def build_jitc(force: bool = False, verbose: bool = False) -> str:
+    """mpc_jitc: hiprtc in a process of its own (csrc/mpc_jit.h starts it when a module sequence has no built-in kernel)."""
+    src = os.path.join(CSRC, "mpc_jitc.cpp")
+    if not force and _newer(JITC, [src]):
+        return JITC
+    rocm = os.path.dirname(os.path.dirname(HIPCC)) if os.path.sep in HIPCC else "/opt/rocm"
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"), src,
+           "-L", os.path.join(rocm, "lib"), "-lhiprtc", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}", "-o", JITC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return JITC
+
+
 def build_cli(force: bool = False, verbose: bool = False) -> str:
     """bin/compressor: the reference's CLI (src/main.cpp) over libmpc_hip.so."""
     if not os.path.isdir(HOST):
@@ -89,6 +104,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_lib(force, verbose)
     build_lib(force, verbose, test=True)
+    build_jitc(force, verbose)
     build_cli(force, verbose)
 
 

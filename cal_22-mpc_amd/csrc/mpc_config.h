@@ -286,13 +286,13 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     P.byte_major = bm0 ? 1 : 0;
     if (bm0) P.runtime_only = 1;
     // any root for OneBase / DiffBase / WeightBase: the residue array is the natural one with bytes 0..root
-    // rotated by one position (ResidueModule.cpp:24-39).  Roots 1..15 (the rotation stays inside the first row of
-    // the scanned array) and tables that stop after a whole number of bit planes run on the unrolled kernels'
-    // general-layout twins; anything else on the run-time module loop
+    // rotated by one position (ResidueModule.cpp:24-39).  Roots 1..15 (the rotation stays inside the first row of the
+    // scanned array) and truncated plane-major tables whose row 0 is complete (TableSize >= 16) run on the unrolled
+    // kernels' general-layout twins; roots above 15, the byte-major order and tables of fewer than 16 entries on the
+    // run-time module loop
     f.root = m.root;
     if (m.root != 0 || m.table_size != 8 * L) {
-      const bool whole_planes = m.table_size == 8 * L || (m.table_size >= L && m.table_size % L == 0);
-      if (m.root <= 15 && whole_planes && !bm0) P.gen_layout = 1;
+      if (m.root <= 15 && !bm0 && m.table_size >= 16) P.gen_layout = 1;
       else P.runtime_only = 1;
     }
     f.cx = m.consecutive_xor ? 1 : 0;

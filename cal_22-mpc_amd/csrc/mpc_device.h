@@ -67,8 +67,8 @@ struct MpcVpcParams {
   int32_t start;        /* module index of the first PredComp module (1 or 2) */
   int32_t has_aws;      /* module 1 is AllWordSame */
   int32_t hist_bins;    /* bins per cluster */
-  int32_t runtime_only; /* fast path, but only through the run-time module loop: a RootIndex above 15, a scan table truncated
-                           inside a bit plane, the byte-major order */
+  int32_t runtime_only; /* fast path, but only through the run-time module loop: a RootIndex above 15, the byte-major order, a
+                           scan table of fewer than 16 entries */
   int32_t tab_words;    /* number of dwords in tab */
   int32_t trunc_off;    /* truncated plane-major scan table (TableSize < 8 L, the same for every module): dword offset in
                            tab of L/4 mask words (the bits of the XORed residue bytes that are scanned); -1: full table */
@@ -80,10 +80,10 @@ struct MpcVpcParams {
   const uint32_t *tab;  /* fast path dword tables (device) */
   const uint8_t *gtab;  /* generic path byte tables (device) */
   int32_t gtab_bytes;   /* size of gtab; the generic kernel keeps a copy in LDS when it fits */
-  int32_t gen_layout;   /* 1: some RootIndex is 1..15 and / or the plane-major scan table stops after a whole number of bit
-                           planes (TableSize = k L, k = 1..7): the unrolled kernels' general-layout twins take it */
+  int32_t gen_layout;   /* 1: some RootIndex is 1..15 and / or the plane-major scan table is truncated (16 <= TableSize < 8 L):
+                           the unrolled kernels' general-layout twins take it */
   uint32_t plane_mask;  /* the scanned bit planes of a residue byte, in every byte (0xffffffff: all; TableSize = 6 L: 0xfcfcfcfc);
-                           meaningful when trunc_off < 0 or gen_layout */
+                           0xffffffff also for a table cut inside a plane, whose per-word masks sit at trunc_off */
   int32_t reserved3;
 };
 

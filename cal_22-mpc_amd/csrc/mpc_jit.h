@@ -4,8 +4,8 @@
 // The library ships the unrolled kernels for 13 module sequences (mpc_vpc_lane.hip, MPC_LANE_SEQUENCES); any other
 // sequence of OneBase / ConsecutiveBase / DiffBase / WeightBase modules used to fall back to the run-time module loop
 // at about 0.3 of the HBM peak.  The group code is a template over the sequence, so the missing
-// instantiation is compiled when the configuration is loaded: hiprtc (the ROCm run-time compiler, loaded with dlopen:
-// the library does not depend on it) compiles mpc_vpc_lane.hip -- the very source the built-in kernels come from, read
+// instantiation is compiled when the configuration is loaded: hiprtc (the ROCm run-time compiler; in a helper process,
+// mpc_jitc, so that the library neither links it nor shares a process with it) compiles mpc_vpc_lane.hip -- the very source the built-in kernels come from, read
 // from the csrc/ directory next to the library -- with the sequence as template arguments, the code object is loaded
 // with hipModuleLoadData and kept in the handle; a copy goes to a cache directory keyed by a hash of the sources, the
 // options and the compiler version, so that the next process skips the compilation (about 3 s).  Nothing here is a
@@ -13,18 +13,25 @@
 // the run-time module loop as before and a line on stderr says why.
 //
 //   MPC_JIT=0            never compile at run time
+//   MPC_JITC=PATH        the helper program (default: mpc_jitc next to the library; without one hiprtc is dlopen'ed here)
 //   MPC_JIT_SRC=DIR      the kernel sources (default: <directory of libmpc_hip*.so>/csrc)
 //   MPC_JIT_CACHE=DIR    code object cache (default: $XDG_CACHE_HOME/mpc_hip or ~/.cache/mpc_hip); "" = no cache
 #pragma once
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <signal.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
+#include <fcntl.h>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -189,12 +196,82 @@ inline std::string source_dir()
   return src_env ? std::string(src_env) : detail::dir_of_this_library() + "/csrc";
 }
 
-// hiprtc: the sequence's translation unit -> a gfx950 code object.  Needs no device (`arch` names the target), which
-// is how the CPU test suite checks that the kernel source still compiles this way (mpc_jit_compile_check).
+// The compiler runs in a process of its own (mpc_jitc, built next to the library; MPC_JITC names another one): a host
+// application may carry its own copy of the ROCm compiler libraries (a PyTorch wheel bundles libhiprtc / libamd_comgr),
+// two LLVMs in one process are asking for trouble, and a fatal compiler error must not take the application down.
+// Returns 1 = code object read back, 0 = the helper ran and failed (why), -1 = no helper to start.
+inline int compile_in_helper(const std::string &source, const std::string &arch, const std::string &src_dir, std::string &code,
+                             std::string &why)
+{
+  const char *env = std::getenv("MPC_JITC");
+  const std::string helper = env ? std::string(env) : detail::dir_of_this_library() + "/mpc_jitc";
+  if (::access(helper.c_str(), X_OK) != 0) return -1;
+  const char *tmp_env = std::getenv("TMPDIR");
+  char stem[512];
+  std::snprintf(stem, sizeof stem, "%s/mpc_jit_%ld_%llx", (tmp_env && *tmp_env) ? tmp_env : "/tmp", (long)getpid(),
+                detail::fnv1a(source) ^ (unsigned long long)::time(nullptr));
+  const std::string in = std::string(stem) + ".hip", outp = std::string(stem) + ".hsaco", logp = std::string(stem) + ".log";
+  {
+    std::ofstream f(in, std::ios::binary);
+    f << source;
+    if (!f) { why = "cannot write " + in; return 0; }
+  }
+  posix_spawn_file_actions_t fa;
+  posix_spawn_file_actions_init(&fa);
+  posix_spawn_file_actions_addopen(&fa, 2, logp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+  posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
+  char *argv[] = {const_cast<char *>(helper.c_str()), const_cast<char *>(in.c_str()), const_cast<char *>(arch.c_str()),
+                  const_cast<char *>(src_dir.c_str()), const_cast<char *>(outp.c_str()), nullptr};
+  // the child gets this process's environment minus preloaded libraries (a profiler's, a sanitizer's): it only compiles
+  std::vector<std::string> keep;
+  for (char **e = environ; e && *e; e++)
+    if (std::strncmp(*e, "LD_PRELOAD=", 11) != 0) keep.push_back(*e);
+  std::vector<char *> envp;
+  for (std::string &e : keep) envp.push_back(&e[0]);
+  envp.push_back(nullptr);
+  pid_t pid = 0;
+  const int rc = posix_spawn(&pid, helper.c_str(), &fa, nullptr, argv, envp.data());
+  posix_spawn_file_actions_destroy(&fa);
+  int result = 0;
+  if (rc != 0) {
+    why = "cannot start " + helper;
+    result = -1;
+  } else {
+    int status = 0;
+    bool done = false;
+    for (int waited = 0; waited < 3000; waited++) {          // up to 5 minutes
+      const pid_t w = ::waitpid(pid, &status, WNOHANG);
+      if (w == pid || (w < 0 && errno != EINTR)) { done = true; break; }
+      struct timespec ts = {0, 100 * 1000 * 1000};
+      ::nanosleep(&ts, nullptr);
+    }
+    if (!done) {
+      ::kill(pid, SIGKILL);
+      (void)::waitpid(pid, &status, 0);
+      why = "the compiler process did not finish";
+    } else if (WIFEXITED(status) && WEXITSTATUS(status) == 0 && detail::read_file(outp, code) && !code.empty()) {
+      result = 1;
+    } else {
+      std::string log;
+      (void)detail::read_file(logp, log);
+      why = "compilation failed (" + helper + "): " + log.substr(0, 1500);
+    }
+  }
+  (void)::unlink(in.c_str());
+  (void)::unlink(outp.c_str());
+  (void)::unlink(logp.c_str());
+  return result;
+}
+
+// the sequence's translation unit -> a gfx950 code object.  Needs no device (`arch` names the target), which is how
+// the CPU test suite checks that the kernel source still compiles this way (mpc_jit_compile_check).  Through the helper
+// process; in this process (hiprtc loaded with dlopen) only when there is no helper to start.
 inline bool compile(const std::string &source, const std::string &arch, const std::string &src_dir, std::string &code, std::string &why)
 {
+  const int h = compile_in_helper(source, arch, src_dir, code, why);
+  if (h >= 0) return h == 1;
   detail::Rtc &rtc = detail::rtc();
-  if (!rtc.ok()) { why = "libhiprtc.so could not be loaded"; return false; }
+  if (!rtc.ok()) { why = "neither mpc_jitc (next to the library) nor libhiprtc.so is available"; return false; }
   hiprtcProgram prog = nullptr;
   if (rtc.create(&prog, source.c_str(), "mpc_jit_sequence.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { why = "hiprtcCreateProgram failed"; return false; }
   const std::string o_arch = "--offload-arch=" + arch, o_inc = "-I" + src_dir;
@@ -239,10 +316,11 @@ inline bool build(const MpcVpcParams &P, int testing, Kernels &out, std::string 
   const std::string source = source_of(P, smem, testing);
 
   // ---- cache: keyed by everything the code object depends on ----
-  int vmaj = 0, vmin = 0;
-  if (detail::rtc().version) (void)detail::rtc().version(&vmaj, &vmin);
+  // (the compiler's version enters through the HIP runtime's: they are installed together)
+  int rtv = 0;
+  (void)hipRuntimeGetVersion(&rtv);
   char key[32];
-  std::snprintf(key, sizeof key, "%016llx", detail::fnv1a(source + all_sources + "|" + arch + "|" + std::to_string(vmaj) + "." + std::to_string(vmin)));
+  std::snprintf(key, sizeof key, "%016llx", detail::fnv1a(source + all_sources + "|" + arch + "|" + std::to_string(rtv)));
   const std::string cdir = detail::cache_dir();
   const std::string cpath = cdir.empty() ? "" : cdir + "/lane_" + key + ".hsaco";
   auto load = [&](const std::string &code) -> hipError_t {

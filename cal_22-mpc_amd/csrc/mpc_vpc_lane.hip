@@ -56,7 +56,8 @@ struct Lane {
   u32 x[W];    // the line
   u32 b0;      // byte 0 = root (RootIndex 0)
   u32 rootb;   // root replicated into 4 bytes
-  bool gen;    // a constant of the instantiation: general layout (a RootIndex of 1..15 per module, whole-plane truncation)
+  bool gen;    // a constant of the instantiation: general layout (a RootIndex of 0..15 per module, truncated plane-major tables)
+  ctab_t trunc;  // general layout, a table cut inside a bit plane: per residue word the bits that are scanned (else null)
 };
 
 // ---- general layout (the GEN twins of the unrolled kernels) ---------------------------------------------------------
@@ -66,6 +67,9 @@ struct Lane {
 // With the root inside the first 16 bytes that rotation stays inside residue words 0..3 = row 0 of every bit plane, so
 //  * the row-0 prefilters need no rotation at all (they OR the MSBs of bytes 0..15: the same set of bytes),
 //  * a full evaluation rotates four words (two instructions each).
+// (Any root -- the word picked among all W, a wave-uniform test per rotated word, the prefilter corrected for a root
+// outside row 0 -- was measured too: 33 spilled VGPRs and 334 spilled SGPRs in the four-module twin.  Roots above 15
+// stay on the run-time loop.)
 // line[root] in every byte
 template <int W>
 __device__ __forceinline__ u32 lane_root_bytes(const Lane<W> &c, int root)
@@ -379,7 +383,7 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
     u32 r[W], root_r;
     lane_residue<W, KIND>(c, P.fm[Q], lane_tab(P), r, root_r);
     if (c.gen && P.fm[Q].root != 0) lane_root_to_front<W, W>(c, P.fm[Q].root, r);
-    const u32 z = lane_leading_zero_rows<W>(r, nullptr, c.gen ? P.plane_mask : ~0u);
+    const u32 z = lane_leading_zero_rows<W>(r, c.gen ? c.trunc : nullptr, c.gen ? P.plane_mask : ~0u);
     if (!any_full) {
       // the first module evaluated for the group (wave-uniform): it is the winner so far, nothing to select
       best.z = z;
@@ -850,7 +854,8 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
   u32 sum_r = 0, sum_r2 = 0;        // residue statistics of this line (VPC.cpp:417-443)
 
   // truncated scan table (run-time loop only): per residue word the bits that are scanned
-  ctab_t scan_mask = (NPT == 0 && P.trunc_off >= 0) ? lane_tab(P) + P.trunc_off : nullptr;
+  ctab_t scan_mask = ((NPT == 0 || (GEN && P.plane_mask == ~0u)) && P.trunc_off >= 0) ? lane_tab(P) + P.trunc_off : nullptr;
+  c.trunc = GEN ? scan_mask : nullptr;
   if (need_mask) {     // wave-uniform: some line needs the prediction modules
     c.b0 = c.x[0] & 0xffu;
     c.rootb = perm(c.x[0], c.x[0], 0u);
@@ -895,7 +900,7 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
         t[e] = best.r[e] ^ (e == 0 ? (f & 0xffffff00u) : f);
       }
     }
-    if (NPT == 0 && scan_mask) {
+    if ((NPT == 0 || GEN) && scan_mask) {      // (wave-uniform) a table cut inside a bit plane: per-word masks
 #pragma unroll
       for (int e = 0; e < W; e++) t[e] &= scan_mask[e];
     }

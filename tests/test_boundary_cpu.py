@@ -54,7 +54,7 @@ def test_custom_encoding_bits_and_generic_classification(mpc, configs):
     cfg = configs.probe_config(64, encoding_bits=[2, 1, 3, 4, 4, 5, 5])
     d = mpc.describe_config(cfg)
     assert d["enc_bits"] == [2, 1, 3, 4, 4, 5, 5] and d["hist_bins"] == 512 + 5 + 1
-    # a root of 1..15 / a plane-major table that stops after whole bit planes -> the unrolled kernels' general-layout twins
+    # a root of 1..15 / a truncated plane-major table -> the unrolled kernels' general-layout twins
     cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, root=7)])
     d = mpc.describe_config(cfg)
     assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "unrolled" and d["general_layout"] == "yes"
@@ -64,15 +64,16 @@ def test_custom_encoding_bits_and_generic_classification(mpc, configs):
                                                                                 "Cols": [i % 64 for i in range(ts)]})])
     d = mpc.describe_config(cfg)
     assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "unrolled" and d["general_layout"] == "yes"
-    # a root above 15 / a table cut inside a bit plane -> still the fast kernel, through its run-time module loop
+    # a root above 15 / a table without a complete first row -> still the fast kernel, through its run-time module loop
     cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, root=16)])
     d = mpc.describe_config(cfg)
     assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "run-time loop" and d["general_layout"] == "no"
-    ts = 300
-    cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, scan={"TableSize": ts, "Rows": [i // 64 for i in range(ts)],
-                                                                                "Cols": [i % 64 for i in range(ts)]})])
-    d = mpc.describe_config(cfg)
-    assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "run-time loop"
+    for ts, general in ((300, True), (16, True), (12, False)):      # cut inside a bit plane; one complete row; less than a row
+        cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, scan={"TableSize": ts, "Rows": [i // 64 for i in range(ts)],
+                                                                                    "Cols": [i % 64 for i in range(ts)]})])
+        d = mpc.describe_config(cfg)
+        assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == ("unrolled" if general else "run-time loop"), (ts, d)
+        assert d["general_layout"] == ("yes" if general else "no"), (ts, d)
     # permuted scan table -> generic kernel
     scan = configs.plane_major_scan(64)
     scan["Rows"][0], scan["Rows"][100] = scan["Rows"][100], scan["Rows"][0]

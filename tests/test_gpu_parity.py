@@ -260,11 +260,12 @@ def test_vpc_fast_path_nonzero_root_and_truncated_scan(mpc, oracle, configs, tra
 
 @pytest.mark.parametrize("L", [32, 64, 128])
 def test_vpc_general_layout_twins(mpc, oracle, configs, traces, L):
-    """RootIndex 1..15 and scan tables that stop after a whole number of bit planes (TableSize = k L) keep the UNROLLED
+    """RootIndex 1..15 and truncated plane-major scan tables (16 <= TableSize < 8 L: whole bit planes through one mask,
+    tables cut inside a plane through per-word masks) keep the UNROLLED
     kernels (their general-layout twins, vpc_lane_gen_kernel: the same row-0 prefilters and line ring; round 2 sent these
     to the run-time module loop at 0.27-0.33 of the peak).  Module sequences with an instantiation: the probe's four
     predictors with 4- and 8-byte-back tables, their non-periodic form (a root outside word 0 breaks the period), single
-    models.  With per-line outputs and in statistics-only mode; a root above 15 or a table cut inside a plane still takes
+    models.  With per-line outputs and in statistics-only mode; a root above 15 or a table without a complete first row still takes
     the run-time loop.  ResidueModule.cpp:24-39 (root first), ScanModule.cpp:13-19 (untouched cells stay zero)."""
     rng = np.random.default_rng(300 + L)
     lines = np.concatenate([traces.structured(5000, L, seed=23), traces.mixed(2500, L), traces.random_u32(800, L),
@@ -307,10 +308,12 @@ def test_vpc_general_layout_twins(mpc, oracle, configs, traces, L):
     for mods in ([az, aws, configs.one_base(L, 11, True, trunc(6 * L))], [az, configs.diff_base(L, prev4, d1, 2, True)],
                  [az, aws, configs.weight_base(L, prev8, w2, 5, False, trunc(3 * L))], [az, aws, configs.one_base(L, 7, False), configs.consecutive_base(L, 0, True)]):
         check(configs.make_config(L, mods), True, 5000)
+    # tables cut inside a bit plane (per-word masks), down to a single complete row
+    for roots, ts in (((0, 0, 0), 6 * L + 8), ((6, 2, 1), 4 * L + 7), ((0, 0, 0), 8 * L - 24), ((0, 3, 0), 16), ((9, 0, 0), L + 20)):
+        check(probe(roots, ts), True, 5000)
     # outside the twins' reach: the run-time loop
     check(probe((16, 0, 0), None), False, 3000)
-    check(probe((0, 0, 0), 6 * L + 8), False, 3000)
-    check(probe((0, 0, 0), 16), False, 3000)
+    check(probe((0, 0, 0), 8), False, 3000)
 
 
 @pytest.mark.parametrize("L", [32, 64, 128])
