@@ -29,6 +29,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cerrno>
 #include <cstring>
 #include <fcntl.h>
@@ -207,9 +208,10 @@ inline int compile_in_helper(const std::string &source, const std::string &arch,
   const std::string helper = env ? std::string(env) : detail::dir_of_this_library() + "/mpc_jitc";
   if (::access(helper.c_str(), X_OK) != 0) return -1;
   const char *tmp_env = std::getenv("TMPDIR");
+  static std::atomic<unsigned> serial{0};                 // (handles may be created from several threads)
   char stem[512];
-  std::snprintf(stem, sizeof stem, "%s/mpc_jit_%ld_%llx", (tmp_env && *tmp_env) ? tmp_env : "/tmp", (long)getpid(),
-                detail::fnv1a(source) ^ (unsigned long long)::time(nullptr));
+  std::snprintf(stem, sizeof stem, "%s/mpc_jit_%ld_%u_%llx", (tmp_env && *tmp_env) ? tmp_env : "/tmp", (long)getpid(),
+                serial.fetch_add(1u), detail::fnv1a(source) ^ (unsigned long long)::time(nullptr));
   const std::string in = std::string(stem) + ".hip", outp = std::string(stem) + ".hsaco", logp = std::string(stem) + ".log";
   {
     std::ofstream f(in, std::ios::binary);
