@@ -418,7 +418,7 @@ def main():
         check_known_ratio(args.algo, args.workload, L, n, ratio)
 
     kernel_name = kernel_label(mpc, ev, args.algo, L)
-    power = PowerProbe(torch, local_rank) if world == 1 else None
+    power = PowerProbe(torch, local_rank) if (world == 1 and not args.no_workloads) else None      # (not under tools/profile_round.sh)
     headline_power = power.run(torch, lambda: ev.compress_device(buf.data_ptr(), n, stream=sp), stream, 1.5) if power else None
 
     # ---- sub-records (not part of the timed region above) ----
