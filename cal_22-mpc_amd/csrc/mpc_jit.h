@@ -15,6 +15,7 @@
 //   MPC_JIT=0            never compile at run time
 //   MPC_JITC=PATH        the helper program (default: mpc_jitc next to the library; without one hiprtc is dlopen'ed here)
 //   MPC_JIT_SRC=DIR      the kernel sources (default: <directory of libmpc_hip*.so>/csrc)
+//   MPC_JIT_DEBUG=1      say on stderr where the compilation ran
 //   MPC_JIT_CACHE=DIR    code object cache (default: $XDG_CACHE_HOME/mpc_hip or ~/.cache/mpc_hip); "" = no cache
 #pragma once
 #include <dlfcn.h>
@@ -271,6 +272,8 @@ inline int compile_in_helper(const std::string &source, const std::string &arch,
 inline bool compile(const std::string &source, const std::string &arch, const std::string &src_dir, std::string &code, std::string &why)
 {
   const int h = compile_in_helper(source, arch, src_dir, code, why);
+  if (std::getenv("MPC_JIT_DEBUG"))
+    std::fprintf(stderr, "libmpc_hip: run-time compilation %s\n", h == 1 ? "in the helper process: ok" : h == 0 ? "in the helper process: FAILED" : "in this process (no helper)");
   if (h >= 0) return h == 1;
   detail::Rtc &rtc = detail::rtc();
   if (!rtc.ok()) { why = "neither mpc_jitc (next to the library) nor libhiprtc.so is available"; return false; }
