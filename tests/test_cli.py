@@ -276,6 +276,35 @@ def test_cli_generic_kernel_is_announced(cli, configs, traces, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_module_sequence_compiled_at_creation(cli, oracle, configs, traces, tmp_path):
+    """The C++ driver (no Python, no PyTorch in the process) on a configuration whose module sequence has no built-in
+    kernel: the library compiles it when `comp::VPC` is constructed (helper process `mpc_jitc`, DESIGN 4.1e); the ratio the
+    reference's `compressLines` prints is the oracle's; with MPC_JIT=0 the run-time loop gives the same text."""
+    L = 64
+    d = tmp_path / "ds"
+    d.mkdir()
+    lines = np.concatenate([traces.structured(3000, L, seed=9), traces.mixed(1500, L), traces.random_u32(500, L)])
+    p = traces.save_npy(str(d / "t.npy"), lines)
+    prev1 = [max(i - 1, 0) for i in range(L)]
+    prev4 = [max(i - 4, 0) for i in range(L)]
+    cfg = configs.make_config(L, [{"name": "AllZero"}, configs.consecutive_base(L, 0, True), configs.diff_base(L, prev1, [2] * L, 3, False),
+                                  configs.weight_base(L, prev4, [[1.0, 0.5][i % 2] for i in range(L)], 0, True), configs.one_base(L, 7, True)])
+    cfg_path = configs.write_config(cfg, str(tmp_path / "seq.json"))
+    o = oracle.VpcOracle(cfg)
+    o.compress(lines[:-1])                               # the reference driver drops the last row
+    want = "comp.ratio: " + fmt_double(o.st.comp_ratio)
+    outs = []
+    for jit in ("1", "0"):
+        env = dict(os.environ, MPC_JIT=jit, MPC_JIT_DEBUG="1", MPC_JIT_CACHE=str(tmp_path / "cache"))
+        r = subprocess.run([cli, "-a", "VPC", "-i", p, "-c", cfg_path, "-o", str(tmp_path)], cwd=BIN, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert want in r.stdout, (want, r.stdout[-300:])
+        assert ("run-time compilation in the helper process: ok" in r.stderr) == (jit == "1"), r.stderr[-500:]
+        outs.append(open(str(tmp_path / "seq_results.csv")).read().strip().split("\n")[-1])      # (the file is appended to, as in the reference)
+    assert outs[0] == outs[1] and outs[0].startswith("ds_t,")
+
+
+@pytest.mark.gpu
 def test_cli_line_size_mismatch_is_an_error(cli, configs, traces, tmp_path):
     d = tmp_path / "ds"
     d.mkdir()
