@@ -1362,8 +1362,13 @@ hipError_t lane_launch(const uint4 *l, u32 n_lines, u64 first_line, const MpcVpc
 #ifndef MPC_DEV_ONLY64     // development builds (tools/ab.py): 64-byte lines only (or 128 with MPC_DEV_ALSO128), seconds to compile
   case 32: MPC_LAUNCH(8); break;
   case 128: MPC_LAUNCH(32); break;
-#elif defined(MPC_DEV_ALSO128)
+#else
+#if defined(MPC_DEV_ALSO128)
   case 128: MPC_LAUNCH(32); break;
+#endif
+#if defined(MPC_DEV_ALSO32)
+  case 32: MPC_LAUNCH(8); break;
+#endif
 #endif
   case 64: MPC_LAUNCH(16); break;
 #endif
@@ -1396,6 +1401,8 @@ static bool lane_has_line_size(int L)
   return L == 4 * MPC_LANE_W;
 #elif defined(MPC_DEV_ONLY64) && defined(MPC_DEV_ALSO128)
   return L == 64 || L == 128;
+#elif defined(MPC_DEV_ONLY64) && defined(MPC_DEV_ALSO32)
+  return L == 64 || L == 32;
 #elif defined(MPC_DEV_ONLY64)
   return L == 64;
 #else

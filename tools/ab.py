@@ -72,11 +72,12 @@ if os.environ.get("AB_CHECK") == "1":
     res["parity"] = ok
     ev.close()
 W = {"random_u32": ("random_u32", 64), "sine_f32": ("sine_f32", 64), "mixed": ("mixed", 64), "zeros": ("zeros", 64),
-     "pointers_u64_128": ("pointers_u64", 128)}
+     "pointers_u64_128": ("pointers_u64", 128), "random_u32_32": ("random_u32", 32), "mixed_32": ("mixed", 32)}
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
 for w in [x for x in workloads if x]:
     kind, L = W[w]
+    n = int(os.environ["AB_LINES"]) * 64 // L
     buf = torch.empty(n * L, dtype=torch.uint8, device=dev)
     mpc.synth_fill(buf.data_ptr(), n, L, kind, first_line=0)
     torch.cuda.synchronize()
