@@ -433,6 +433,7 @@ def main():
     # ... and the random-u32 trace through configurations of other layouts (general-layout twins, run-time compiled sequence)
     layouts = None
     if world == 1 and not args.no_workloads and args.workload == "random_u32" and L == 64:
+        os.environ.setdefault("MPC_JIT_CACHE", "")      # (a measurement run leaves no code-object cache behind; ~3 s of compilation)
         mpc.synth_fill(buf.data_ptr(), n, L, kind, first_line=0)
         torch.cuda.synchronize()
         layouts = [time_layout(torch, mpc, buf, stream, local_rank, name, cfg, n, L) for name, cfg in layout_configs(configs, L)]

@@ -76,6 +76,13 @@ def _shm_names():
 
 def pytest_sessionstart(session):
     session.config._mpc_shm_before = _shm_names()
+    # Code objects of module sequences compiled at handle creation (csrc/mpc_jit.h) go to a cache directory; the default is
+    # under $HOME and would stay behind on the box.  The session (and the child processes its tests start) gets one of its
+    # own, removed when the session ends.
+    if "MPC_JIT_CACHE" not in os.environ:
+        import tempfile
+        session.config._mpc_jit_cache = tempfile.mkdtemp(prefix="mpc_jit_cache_")
+        os.environ["MPC_JIT_CACHE"] = session.config._mpc_jit_cache
     # Orphans come home.  A helper whose parent exits first (the resource tracker of a torch.distributed.run agent, for
     # one) is re-parented to process 1, which on the GPU boxes never reaps: it stays behind as a zombie after the
     # session (seen in round 2: "the box could not be shown clean").  As a child subreaper this process inherits such
@@ -114,9 +121,14 @@ def _stop_resource_tracker():
 
 
 def pytest_sessionfinish(session, exitstatus):
+    import shutil
     import signal
     import time
     me = os.getpid()
+    jit_cache = getattr(session.config, "_mpc_jit_cache", None)
+    if jit_cache:
+        shutil.rmtree(jit_cache, ignore_errors=True)
+        os.environ.pop("MPC_JIT_CACHE", None)
     _stop_resource_tracker()
     # helper daemons of multiprocessing / torch end with this process; anything else is a worker that leaked
     benign = ("resource_tracker", "torch_shm_manag")
