@@ -379,6 +379,15 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     }
   }
   if (P.runtime_only) P.gen_layout = 0;
+  if (plan.fast && P.byte_major && cfg.n_pred > 0) {
+    bool roots0 = true;
+    for (int q = 0; q < cfg.n_pred; q++) roots0 = roots0 && P.fm[q].root == 0;
+    const int ts = cfg.modules[(size_t)cfg.start].table_size;
+    if (roots0 && ts >= 16) {
+      P.bm_unrolled = 1;
+      P.gen_layout = ts != 8 * L ? 1 : 0;      // (the truncation masks of the general layout)
+    }
+  }
   P.plane_mask = ~0u;
   if (plan.fast && cfg.n_pred > 0 && !P.byte_major) {
     const int ts = cfg.modules[(size_t)cfg.start].table_size;

@@ -84,7 +84,9 @@ struct MpcVpcParams {
                            the unrolled kernels' general-layout twins take it */
   uint32_t plane_mask;  /* the scanned bit planes of a residue byte, in every byte (0xffffffff: all; TableSize = 6 L: 0xfcfcfcfc);
                            0xffffffff also for a table cut inside a plane, whose per-word masks sit at trunc_off */
-  int32_t reserved3;
+  int32_t bm_unrolled;  /* 1: byte-major order with every RootIndex 0 and a complete first row (TableSize >= 16): no built-in
+                           kernel (runtime_only stays 1), but the unrolled kernels can be compiled for it at handle creation
+                           (mpc_jit.h, -DMPC_JIT_BM); gen_layout then says whether the table is truncated */
 };
 
 /* Device-side raw statistics (uint64 each):

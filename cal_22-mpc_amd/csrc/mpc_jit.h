@@ -3,7 +3,8 @@
 //
 // The library ships the unrolled kernels for 13 module sequences (mpc_vpc_lane.hip, MPC_LANE_SEQUENCES); any other
 // sequence of OneBase / ConsecutiveBase / DiffBase / WeightBase modules used to fall back to the run-time module loop
-// at about 0.3 of the HBM peak.  The group code is a template over the sequence, so the missing
+// at about 0.3 of the HBM peak -- as did every configuration with the byte-major scan order, for which
+// the library has no unrolled kernel at all (compiled here with -DMPC_JIT_BM=1).  The group code is a template over the sequence, so the missing
 // instantiation is compiled when the configuration is loaded: hiprtc (the ROCm run-time compiler; in a helper process,
 // mpc_jitc, so that the library neither links it nor shares a process with it) compiles mpc_vpc_lane.hip -- the very source the built-in kernels come from, read
 // from the csrc/ directory next to the library -- with the sequence as template arguments, the code object is loaded
@@ -78,9 +79,9 @@ inline bool eligible(const MpcVpcParams &P, bool fast)
 {
   const char *env = std::getenv("MPC_JIT");
   if (env && std::strcmp(env, "0") == 0) return false;
-  if (!fast || P.runtime_only || P.n_pred < 1 || P.n_pred > kMaxModules) return false;
+  if (!fast || (P.runtime_only && !P.bm_unrolled) || P.n_pred < 1 || P.n_pred > kMaxModules) return false;
   if (!(P.L == 32 || P.L == 64 || P.L == 128)) return false;
-  if (mpc_vpc_lane_unrolled(&P)) return false;            // built in
+  if (mpc_vpc_lane_unrolled(&P)) return false;            // built in (never the byte-major order)
   unsigned ring_cfg = 0;
   return mpc_vpc_lane_ring_plan(&P, &ring_cfg) != 0;       // the rings fit beside the histogram
 }
@@ -175,6 +176,7 @@ inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testi
   const std::string targs = std::to_string(W) + ", OUT_, " + (P.gen_layout ? "true" : "false") + ", " + kinds_of(P);
   std::ostringstream s;
   s << "#define MPC_LANE_JIT 1\n"
+    << "#define MPC_JIT_BM " << (P.bm_unrolled ? 1 : 0) << "\n"
     << "#define MPC_TESTING " << testing << "\n"
     << "#include \"mpc_vpc_lane.hip\"\n"
     << "#define MPC_JIT_KERNEL(NAME, OUT_) \\\n"

@@ -31,6 +31,13 @@
 #include "mpc_kernel_common.h"
 #include "mpc_ring.h"
 
+// 1 only in a translation unit that mpc_jit.h hands to the run-time compiler for a configuration with the BYTE-MAJOR scan
+// order (scanned bit i = plane i % 8 of byte i / 8: row r of the scanned array = XORed residue bytes 2r, 2r+1): the
+// unrolled kernels then use that order's selector, row-0 prefilter (bytes 0 and 1 all zero), certificate and encoder.
+// No built-in kernel is compiled this way.
+#ifndef MPC_JIT_BM
+#define MPC_JIT_BM 0
+#endif
 #ifndef MPC_ABLATE
 #define MPC_ABLATE 0   // development-only timing ablations (tools/ablate.sh); results are WRONG when non-zero
 #endif
@@ -317,6 +324,16 @@ __host__ __device__ static inline size_t lane_stats_smem(int K, int bins)
 // 0..2) is non-zero exactly when every module shows an MSB; if that holds on every needed line, no module
 // but the last can win anywhere in the group -- one ballot instead of one per module (the common case on
 // incompressible data).
+// byte-major order (MPC_JIT_BM; RootIndex 0): row 0 of the scanned array is residue bytes 0 and 1 -- a module other than the
+// last can only win if both are zero.  Returns them (non-zero: the module cannot win on this line).
+template <int W, int KIND>
+__device__ __forceinline__ u32 lane_row0_bm(const Lane<W> &c, const MpcFastModule &fm, ctab_t tab)
+{
+  u32 r[W], root_r;
+  lane_residue<W, KIND, 1>(c, fm, tab, r, root_r);
+  return r[0] & (c.trunc ? (c.trunc[0] & 0xffffu) : 0xffffu);
+}
+
 template <int W, int NPT, int Q>
 __device__ __forceinline__ u32 lane_row0_min(const Lane<W> &, const MpcVpcParams &) { return ~0u; }
 
@@ -326,7 +343,7 @@ __device__ __forceinline__ u32 lane_row0_min(const Lane<W> &c, const MpcVpcParam
   if constexpr (Q + 1 == NPT) {
     return ~0u;
   } else {
-    const u32 m = lane_row0<W, KIND, 0, 3>(c, P.fm[Q], lane_tab(P));
+    const u32 m = MPC_JIT_BM ? lane_row0_bm<W, KIND>(c, P.fm[Q], lane_tab(P)) : lane_row0<W, KIND, 0, 3>(c, P.fm[Q], lane_tab(P));
     return min(m, lane_row0_min<W, NPT, Q + 1, REST...>(c, P));
   }
 }
@@ -347,9 +364,9 @@ __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcPar
     u32 bit = 0;
     if constexpr (!(MPC_ABLATE & 8)) {
       // words 0..2 first: on incompressible data 12 bytes almost always show an MSB
-      u32 msb = lane_row0<W, KIND, 0, 3>(c, P.fm[Q], lane_tab(P));
+      u32 msb = MPC_JIT_BM ? lane_row0_bm<W, KIND>(c, P.fm[Q], lane_tab(P)) : lane_row0<W, KIND, 0, 3>(c, P.fm[Q], lane_tab(P));
       if ((__ballot(msb != 0) & need_mask) != need_mask) {
-        msb |= lane_row0<W, KIND, 3, 4>(c, P.fm[Q], lane_tab(P));
+        if (!MPC_JIT_BM) msb |= lane_row0<W, KIND, 3, 4>(c, P.fm[Q], lane_tab(P));
         const u64 pass = ~__ballot(msb != 0) & need_mask;
         if (pass) {
           if (MPC_DEFER_MAX > 0 && W <= 16 && allow_defer && __popcll(pass) <= MPC_DEFER_MAX) {   // (128-byte lines: measured slower)
@@ -369,6 +386,9 @@ __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcPar
   }
 }
 
+template <int W, int NR>
+__device__ __forceinline__ u32 lane_leading_zero_rows_bm(const u32 (&r)[W], ctab_t scan_mask, u32 none);
+
 // Pass 2 (only when pass 1 kept a module): the kept modules and the last one in order,
 // winner updated with bit masks (v_bitop3_b32).
 template <int W, int NPT, int Q>
@@ -383,7 +403,8 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
     u32 r[W], root_r;
     lane_residue<W, KIND>(c, P.fm[Q], lane_tab(P), r, root_r);
     if (c.gen && P.fm[Q].root != 0) lane_root_to_front<W, W>(c, P.fm[Q].root, r);
-    const u32 z = lane_leading_zero_rows<W>(r, c.gen ? c.trunc : nullptr, c.gen ? P.plane_mask : ~0u);
+    const u32 z = MPC_JIT_BM ? lane_leading_zero_rows_bm<W, W>(r, c.gen ? c.trunc : nullptr, 2u * W)
+                             : lane_leading_zero_rows<W>(r, c.gen ? c.trunc : nullptr, c.gen ? P.plane_mask : ~0u);
     if (!any_full) {
       // the first module evaluated for the group (wave-uniform): it is the winner so far, nothing to select
       best.z = z;
@@ -659,6 +680,36 @@ __device__ __forceinline__ bool lane_certified(const u32 (&t)[W])
   return bound >= 32u * W;
 }
 
+// The same certificate for the byte-major order (MPC_JIT_BM): row r = bytes 2r (columns 0..7) and 2r+1 (columns 8..15) of t,
+// two rows per word.  Packed 16-bit minima do the per-row tests: min(a, b) is non-zero exactly when both are.
+typedef unsigned short lane_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 lane_pk_min(u32 a, u32 b)
+{
+  return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(lane_u16x2, a), __builtin_bit_cast(lane_u16x2, b)));
+}
+__device__ __forceinline__ u32 lane_pk_add(u32 a, u32 b)
+{
+  return __builtin_bit_cast(u32, (lane_u16x2)(__builtin_bit_cast(lane_u16x2, a) + __builtin_bit_cast(lane_u16x2, b)));
+}
+template <int W>
+__device__ __forceinline__ bool lane_certified_bm(const u32 (&t)[W])
+{
+  u32 acc = 0;      // per halfword: rows that cost 17 in bits 8.., non-zero rows in bits 0..7
+#pragma unroll
+  for (int e = 0; e < W; e++) {
+    const u32 x = t[e];
+    const u32 front = x & 0x00ff00ffu, back = (x >> 8) & 0x00ff00ffu;      // columns 0..7 / 8..15 of the word's two rows
+    const u32 both = lane_pk_min(front, back);                              // both halves non-zero
+    const u32 c17 = lane_pk_min(both, x & 0x7ffe7ffeu);                     // ... and a bit outside columns 7 / 8
+    // (flags 0 / 1 per row: a 17-bit row counts in bits 8.., a non-zero row in bits 0..7)
+    acc = lane_pk_add(acc, (lane_pk_min(c17, 0x00010001u) << 8) | lane_pk_min(x, 0x00010001u));
+  }
+  const u32 sum = (acc & 0xffffu) + (acc >> 16);
+  const u32 n17 = sum >> 8, nnz = sum & 0xffu;
+  const u32 bound = 10u * n17 + 7u * nnz + (nnz != 2u * W ? 4u : 0u);
+  return bound >= 32u * W;
+}
+
 // Common encoder's row classes for FOUR column groups at once (t = their 16 words): the 16
 // columns are brought into "packed" form -- P[c] holds column c of the four groups, one
 // byte per group, bit 7-p = plane p -- with 4x4 byte transposes, and every step of
@@ -854,7 +905,7 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
   u32 sum_r = 0, sum_r2 = 0;        // residue statistics of this line (VPC.cpp:417-443)
 
   // truncated scan table (run-time loop only): per residue word the bits that are scanned
-  ctab_t scan_mask = ((NPT == 0 || (GEN && P.plane_mask == ~0u)) && P.trunc_off >= 0) ? lane_tab(P) + P.trunc_off : nullptr;
+  ctab_t scan_mask = ((NPT == 0 || (GEN && P.plane_mask == ~0u)) && P.trunc_off >= 0) ? lane_tab(P) + P.trunc_off : nullptr;     // (byte-major: plane_mask is all ones)
   c.trunc = GEN ? scan_mask : nullptr;
   if (need_mask) {     // wave-uniform: some line needs the prediction modules
     c.b0 = c.x[0] & 0xffu;
@@ -912,8 +963,9 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
     // previous group of this wave still had compressible lines it is skipped and the encoder runs
     // straight away (rs.enc_hot, wave-uniform).
     bool open = need;
-    const bool byte_major = NPT == 0 && P.byte_major;              // (no certificate for that order: the encoder always runs)
+    const bool byte_major = (NPT == 0 && P.byte_major) || (MPC_JIT_BM && NPT > 0);    // (run-time loop: no certificate for that order)
     if (!rs.enc_hot && !byte_major) open = need && !lane_certified<W>(t);
+    if (MPC_JIT_BM && NPT > 0 && !rs.enc_hot) open = need && !lane_certified_bm<W>(t);
     if constexpr (MPC_ABLATE & 16) {                  // timing ablation: the certificate stays, the compressible path is cut off
       if (__ballot(open)) E.st.hist[0] = 1u;          // (keeps the certificate alive; results are wrong)
       open = false;

@@ -377,6 +377,25 @@ def test_vpc_sequences_compiled_at_creation(mpc, oracle, configs, traces, L, tmp
             first = run(cfg, "unrolled, compiled at creation")
             assert "cache" not in first, (name, first)
             assert run(cfg, "unrolled, compiled at creation") == "unrolled, compiled at creation (from the cache)"
+    # the byte-major scan order (rows = byte pairs): no built-in kernel has it; with every RootIndex 0 the unrolled kernels are
+    # compiled for it (its own selector, row-0 prefilter, certificate and encoder), full and truncated tables; a root elsewhere
+    # keeps the run-time loop
+    def bytemajor(ts=8 * L):
+        return {"TableSize": ts, "Rows": [i % 8 for i in range(ts)], "Cols": [i // 8 for i in range(ts)]}
+    d1 = [1 if i % 4 == 0 else 0 for i in range(L)]
+    for ts in (8 * L, 8 * L - 20, 5 * L + 3, 24, 16):
+        sb = bytemajor(ts)
+        cfg = configs.make_config(L, [az, aws, configs.one_base(L, 0, True, sb), configs.consecutive_base(L, 0, True, sb),
+                                      configs.diff_base(L, prev4, d1, 0, False, sb), configs.weight_base(L, prev4, w2, 0, True, sb)])
+        d = mpc.describe_config(cfg)
+        assert d["scan_order"] == "byte-major" and d["sequence"] == "unrolled" and d["compiled"] == "at creation", d
+        run(cfg, "unrolled, compiled at creation")
+    sb = bytemajor()
+    run(configs.make_config(L, [az, configs.one_base(L, 0, True, sb), configs.diff_base(L, prev1, diff, 0, False, sb),
+                                configs.weight_base(L, prev4, w3, 0, False, sb), configs.one_base(L, 0, False, sb)]), "unrolled, compiled at creation")
+    run(configs.make_config(L, [az, aws, configs.consecutive_base(L, 0, True, sb)]), "unrolled, compiled at creation")
+    run(configs.make_config(L, [az, aws, configs.one_base(L, 6, True, sb), configs.consecutive_base(L, 0, False, sb)]), "run-time loop")
+    run(configs.make_config(L, [az, aws, configs.one_base(L, 0, True, bytemajor(8)), configs.consecutive_base(L, 0, False, bytemajor(8))]), "run-time loop")
     # switched off: the run-time module loop, same results
     monkeypatch.setenv("MPC_JIT", "0")
     cfg = configs.make_config(L, seqs["OB DF WT OB"](None, (0, 0, 0)))
@@ -1034,6 +1053,20 @@ for L in (64, 32, 128):
         assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all(), (L, roots, ts)
         res["%d/%s/%s" % (L, roots, ts)] = routes(ev)
         ev.close()
+# the byte-major order on kernels compiled at creation (the test library's own code object: its route counters are in)
+L = 64
+bm = {"TableSize": 8 * L, "Rows": [i % 8 for i in range(8 * L)], "Cols": [i // 8 for i in range(8 * L)]}
+prev4 = [max(i - 4, 0) for i in range(L)]; w2 = [[1.0, 0.5][i % 2] for i in range(L)]; d1 = [1 if i % 4 == 0 else 0 for i in range(L)]
+cfg = C.make_config(L, [az, aws, C.one_base(L, 0, True, bm), C.consecutive_base(L, 0, True, bm), C.diff_base(L, prev4, d1, 0, False, bm),
+                        C.weight_base(L, prev4, w2, 0, True, bm)])
+lines = np.concatenate([T.mixed(90001, L), T.structured(30000, L, seed=3), T.random_u32(20000, L), T.mixed(4097, L)])
+ev, o = mpc.VPC(cfg), O.VpcOracle(cfg)
+assert ev.kernel_form.startswith("unrolled, compiled at creation"), ev.kernel_form
+s, k = ev.compress_lines(lines)
+s_ref, k_ref = o.compress(lines)
+assert (s == s_ref).all() and (k == k_ref).all() and (ev.stats_vector() == o.stats_vector()).all()
+res["64/byte-major"] = routes(ev)
+ev.close()
 print("ROUTES " + json.dumps(res))
 """
     res = _run_with_test_library(code, grid_cap=1)

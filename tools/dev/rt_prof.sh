@@ -7,7 +7,7 @@ import csv,glob,sys,collections
 f=glob.glob(sys.argv[1]+'/**/*counter_collection.csv',recursive=True)[0]
 agg=collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if 'vpc_lane' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    if 'vpc_lane' in r['Kernel_Name'] or 'mpc_jit' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
 g=(16<<30)/64/64
 for k,v in sorted(agg.items()): print(f"   {k:20s} {sum(v)/len(v)/g:10.1f} per group of 64 lines ({len(v)} launches)")
 PY
