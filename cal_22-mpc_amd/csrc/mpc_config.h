@@ -379,6 +379,14 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     }
   }
   if (P.runtime_only) P.gen_layout = 0;
+  if (plan.fast && !P.byte_major && cfg.n_pred > 0 && cfg.modules[(size_t)cfg.start].table_size >= 16) {
+    bool far_root = false;
+    for (int q = 0; q < cfg.n_pred; q++) far_root = far_root || P.fm[q].root > 15;
+    if (far_root) {           // (the only reason the built-in twins could not take it)
+      P.anyroot_unrolled = 1;
+      P.gen_layout = 1;
+    }
+  }
   if (plan.fast && P.byte_major && cfg.n_pred > 0) {
     bool roots0 = true;
     for (int q = 0; q < cfg.n_pred; q++) roots0 = roots0 && P.fm[q].root == 0;

@@ -87,6 +87,10 @@ struct MpcVpcParams {
   int32_t bm_unrolled;  /* 1: byte-major order with every RootIndex 0 and a complete first row (TableSize >= 16): no built-in
                            kernel (runtime_only stays 1), but the unrolled kernels can be compiled for it at handle creation
                            (mpc_jit.h, -DMPC_JIT_BM); gen_layout then says whether the table is truncated */
+  int32_t anyroot_unrolled; /* 1: plane-major order, complete first row, some RootIndex above 15: no built-in kernel (runtime_only
+                           stays 1), but the general-layout kernels can be compiled for it at handle creation with the roots as
+                           constants (mpc_jit.h, -DMPC_JIT_ANYROOT); gen_layout is 1 */
+  int32_t reserved4;
 };
 
 /* Device-side raw statistics (uint64 each):

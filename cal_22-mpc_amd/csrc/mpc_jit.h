@@ -74,12 +74,19 @@ inline std::string kinds_of(const MpcVpcParams &P)
   return s;
 }
 
+inline std::string roots_of(const MpcVpcParams &P)
+{
+  std::string s;
+  for (int q = 0; q < P.n_pred; q++) s += (q ? ", " : "") + std::to_string(P.anyroot_unrolled ? P.fm[q].root : 0);
+  return s;
+}
+
 // a fast-path configuration whose sequence has no built-in instantiation but could have one
 inline bool eligible(const MpcVpcParams &P, bool fast)
 {
   const char *env = std::getenv("MPC_JIT");
   if (env && std::strcmp(env, "0") == 0) return false;
-  if (!fast || (P.runtime_only && !P.bm_unrolled) || P.n_pred < 1 || P.n_pred > kMaxModules) return false;
+  if (!fast || (P.runtime_only && !P.bm_unrolled && !P.anyroot_unrolled) || P.n_pred < 1 || P.n_pred > kMaxModules) return false;
   if (!(P.L == 32 || P.L == 64 || P.L == 128)) return false;
   if (mpc_vpc_lane_unrolled(&P)) return false;            // built in (never the byte-major order)
   unsigned ring_cfg = 0;
@@ -177,6 +184,8 @@ inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testi
   std::ostringstream s;
   s << "#define MPC_LANE_JIT 1\n"
     << "#define MPC_JIT_BM " << (P.bm_unrolled ? 1 : 0) << "\n"
+    << "#define MPC_JIT_ANYROOT " << (P.anyroot_unrolled ? 1 : 0) << "\n"
+    << "#define MPC_JIT_ROOTS " << roots_of(P) << "\n"
     << "#define MPC_TESTING " << testing << "\n"
     << "#include \"mpc_vpc_lane.hip\"\n"
     << "#define MPC_JIT_KERNEL(NAME, OUT_) \\\n"

@@ -38,6 +38,13 @@
 #ifndef MPC_JIT_BM
 #define MPC_JIT_BM 0
 #endif
+// 1 only in a translation unit that mpc_jit.h compiles for a configuration with a RootIndex above 15: MPC_JIT_ROOTS then
+// lists every module's root, the group code sees them as constants, and the general form of the root-first rotation (any
+// word, the prefilter corrected for a root outside row 0) folds to a few instructions -- with roots read at run time the
+// same code costs 33 spilled VGPRs.
+#ifndef MPC_JIT_ANYROOT
+#define MPC_JIT_ANYROOT 0
+#endif
 #ifndef MPC_ABLATE
 #define MPC_ABLATE 0   // development-only timing ablations (tools/ablate.sh); results are WRONG when non-zero
 #endif
@@ -57,6 +64,20 @@ __device__ __host__ constexpr int lk_dist(int kind) { return (kind & LK_PW2) ? 2
 // and a vector load's s_waitcnt vmcnt(0) also waits for every line request in flight.
 typedef const u32 __attribute__((address_space(4))) *ctab_t;
 __device__ __forceinline__ ctab_t lane_tab(const MpcVpcParams &P) { return (ctab_t)(u64)P.tab; }
+
+#if MPC_JIT_ANYROOT
+template <int Q>
+__device__ __forceinline__ MpcFastModule lane_fm_const(const MpcVpcParams &P)
+{
+  constexpr int roots[] = {MPC_JIT_ROOTS};
+  MpcFastModule f = P.fm[Q];
+  f.root = roots[Q];
+  return f;
+}
+#define LANE_FM(Q) lane_fm_const<Q>(P)
+#else
+#define LANE_FM(Q) P.fm[Q]
+#endif
 
 template <int W>
 struct Lane {
@@ -85,7 +106,7 @@ __device__ __forceinline__ u32 lane_root_bytes(const Lane<W> &c, int root)
   const int rw = root >> 2;
   u32 xw = 0;
 #pragma unroll
-  for (int e = 0; e < 4; e++) xw = and_or(c.x[e], 0u - (u32)(e == rw), xw);
+  for (int e = 0; e < (MPC_JIT_ANYROOT ? W : 4); e++) xw = and_or(c.x[e], 0u - (u32)(e == rw), xw);     // (a constant root: one word)
   return perm(xw, xw, 0x01010101u * (u32)(root & 3));
 }
 // what OneBase predicts for word e: line[root] everywhere, 0 at the root position itself
@@ -94,13 +115,19 @@ __device__ __forceinline__ u32 lane_onebase_pred(u32 rb, int root, int e)
   const u32 here = (e == (root >> 2)) ? (0xffu << (8 * (root & 3))) : 0u;      // (scalar)
   return rb & ~here;
 }
-// natural residue -> root-first order, words 0..NR-1 (NR <= 4 suffices: root <= 15)
+// row-0 prefilter with a root above 15 (MPC_JIT_ANYROOT): row 0 is the raw root and natural bytes 0..14 -- natural byte 15 has
+// moved to row 1 and does not count
+__device__ __forceinline__ u32 lane_row0_word(u32 msbs, int root, int e)
+{
+  return (MPC_JIT_ANYROOT && e == 3 && root > 15) ? (msbs & 0x00ffffffu) : msbs;
+}
+// natural residue -> root-first order, words 0..NR-1 (run-time roots: NR <= 4 suffices, root <= 15)
 template <int W, int NR>
 __device__ __forceinline__ void lane_root_to_front(const Lane<W> &c, int root, u32 (&r)[W])
 {
   u32 prev = lane_root_bytes<W>(c, root) & 0xff000000u;      // the raw root enters byte 0 of word 0
 #pragma unroll
-  for (int e = 0; e < (NR < 4 ? NR : 4); e++) {
+  for (int e = 0; e < (MPC_JIT_ANYROOT ? NR : (NR < 4 ? NR : 4)); e++) {
     const u32 sh = alignbyte(r[e], prev, 3);                   // the natural bytes one position up
     const int nb = root + 1 - 4 * e;                           // bytes of this word at positions <= root
     const u32 m = nb >= 4 ? ~0u : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
@@ -183,7 +210,7 @@ __device__ __forceinline__ void lane_residue(const Lane<W> &c, const MpcFastModu
     if (c.gen && fm.root != 0) {       // (wave-uniform; GEN twins only)
       const u32 rb = lane_root_bytes<W>(c, fm.root);
 #pragma unroll
-      for (int e = 0; e < NR; e++) r[e] = bsub(c.x[e], e < 4 ? lane_onebase_pred(rb, fm.root, e) : rb);
+      for (int e = 0; e < NR; e++) r[e] = bsub(c.x[e], (MPC_JIT_ANYROOT || e < 4) ? lane_onebase_pred(rb, fm.root, e) : rb);
     } else {
       // predicted = line[0] everywhere; position 0 of the residue array is the raw root
       r[0] = bsub(c.x[0], c.rootb & 0xffffff00u);
@@ -220,7 +247,8 @@ __device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &
     if (c.gen && fm.root != 0) {       // (wave-uniform; GEN twins only)
       const u32 rb = lane_root_bytes<W>(c, fm.root);
 #pragma unroll
-      for (int e = E0; e < E1; e++) m |= msb_of_bsub(c.x[e], lane_onebase_pred(rb, fm.root, e));
+      for (int e = E0; e < E1; e++) m |= lane_row0_word(msb_of_bsub(c.x[e], lane_onebase_pred(rb, fm.root, e)), fm.root, e);
+      if (MPC_JIT_ANYROOT && E0 == 0 && fm.root > 15) m |= rb;            // the raw root sits in row 0
     } else {
 #pragma unroll
       for (int e = E0; e < E1; e++) m |= msb_of_bsub(c.x[e], e ? c.rootb : (c.rootb & 0xffffff00u));
@@ -234,7 +262,8 @@ __device__ __forceinline__ u32 lane_row0(const Lane<W> &c, const MpcFastModule &
   } else {
     ctab_t t = tab + fm.tab_off;
 #pragma unroll
-    for (int e = E0; e < E1; e++) m |= window_residue<W, KIND, false>(c, e, t, fm);
+    for (int e = E0; e < E1; e++) m |= lane_row0_word(window_residue<W, KIND, false>(c, e, t, fm), c.gen ? fm.root : 0, e);
+    if (MPC_JIT_ANYROOT && c.gen && E0 == 0 && fm.root > 15) m |= lane_root_bytes<W>(c, fm.root);     // the raw root sits in row 0
   }
   return m & H80;
 }
@@ -343,7 +372,7 @@ __device__ __forceinline__ u32 lane_row0_min(const Lane<W> &c, const MpcVpcParam
   if constexpr (Q + 1 == NPT) {
     return ~0u;
   } else {
-    const u32 m = MPC_JIT_BM ? lane_row0_bm<W, KIND>(c, P.fm[Q], lane_tab(P)) : lane_row0<W, KIND, 0, 3>(c, P.fm[Q], lane_tab(P));
+    const u32 m = MPC_JIT_BM ? lane_row0_bm<W, KIND>(c, LANE_FM(Q), lane_tab(P)) : lane_row0<W, KIND, 0, 3>(c, LANE_FM(Q), lane_tab(P));
     return min(m, lane_row0_min<W, NPT, Q + 1, REST...>(c, P));
   }
 }
@@ -364,9 +393,9 @@ __device__ __forceinline__ u32 lane_prefilters(const Lane<W> &c, const MpcVpcPar
     u32 bit = 0;
     if constexpr (!(MPC_ABLATE & 8)) {
       // words 0..2 first: on incompressible data 12 bytes almost always show an MSB
-      u32 msb = MPC_JIT_BM ? lane_row0_bm<W, KIND>(c, P.fm[Q], lane_tab(P)) : lane_row0<W, KIND, 0, 3>(c, P.fm[Q], lane_tab(P));
+      u32 msb = MPC_JIT_BM ? lane_row0_bm<W, KIND>(c, LANE_FM(Q), lane_tab(P)) : lane_row0<W, KIND, 0, 3>(c, LANE_FM(Q), lane_tab(P));
       if ((__ballot(msb != 0) & need_mask) != need_mask) {
-        if (!MPC_JIT_BM) msb |= lane_row0<W, KIND, 3, 4>(c, P.fm[Q], lane_tab(P));
+        if (!MPC_JIT_BM) msb |= lane_row0<W, KIND, 3, 4>(c, LANE_FM(Q), lane_tab(P));
         const u64 pass = ~__ballot(msb != 0) & need_mask;
         if (pass) {
           if (MPC_DEFER_MAX > 0 && W <= 16 && allow_defer && __popcll(pass) <= MPC_DEFER_MAX) {   // (128-byte lines: measured slower)
@@ -401,8 +430,8 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
   constexpr bool last = Q + 1 == NPT;
   if (last || (keep_bits & (1u << Q))) {
     u32 r[W], root_r;
-    lane_residue<W, KIND>(c, P.fm[Q], lane_tab(P), r, root_r);
-    if (c.gen && P.fm[Q].root != 0) lane_root_to_front<W, W>(c, P.fm[Q].root, r);
+    lane_residue<W, KIND>(c, LANE_FM(Q), lane_tab(P), r, root_r);
+    if (c.gen && LANE_FM(Q).root != 0) lane_root_to_front<W, W>(c, LANE_FM(Q).root, r);
     const u32 z = MPC_JIT_BM ? lane_leading_zero_rows_bm<W, W>(r, c.gen ? c.trunc : nullptr, 2u * W)
                              : lane_leading_zero_rows<W>(r, c.gen ? c.trunc : nullptr, c.gen ? P.plane_mask : ~0u);
     if (!any_full) {
@@ -410,7 +439,7 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
       best.z = z;
       best.q = Q;
       best.root_r = root_r;
-      best.cx = (u32)P.fm[Q].cx;
+      best.cx = (u32)LANE_FM(Q).cx;
       best.encb = (u32)P.enc_bits[P.start + Q + 1];
 #pragma unroll
       for (int e = 0; e < W; e++) best.r[e] = r[e];
@@ -420,7 +449,7 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
       best.z = mask_sel(m, z, best.z);
       best.q = (int)mask_sel(m, (u32)Q, (u32)best.q);
       best.root_r = mask_sel(m, root_r, best.root_r);
-      best.cx = mask_sel(m, (u32)P.fm[Q].cx, best.cx);
+      best.cx = mask_sel(m, (u32)LANE_FM(Q).cx, best.cx);
       best.encb = mask_sel(m, (u32)P.enc_bits[P.start + Q + 1], best.encb);
 #pragma unroll
       for (int e = 0; e < W; e++) best.r[e] = mask_sel(m, r[e], best.r[e]);
@@ -438,10 +467,10 @@ template <int W, int NPT, int Q, int KIND, int... REST>
 __device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &P, LaneBest<W> &best)
 {
   if constexpr (Q + 1 == NPT) {
-    lane_residue<W, KIND>(c, P.fm[Q], lane_tab(P), best.r, best.root_r);
-    if (c.gen && P.fm[Q].root != 0) lane_root_to_front<W, W>(c, P.fm[Q].root, best.r);
+    lane_residue<W, KIND>(c, LANE_FM(Q), lane_tab(P), best.r, best.root_r);
+    if (c.gen && LANE_FM(Q).root != 0) lane_root_to_front<W, W>(c, LANE_FM(Q).root, best.r);
     best.q = Q;
-    best.cx = (u32)P.fm[Q].cx;
+    best.cx = (u32)LANE_FM(Q).cx;
     best.encb = (u32)P.enc_bits[P.start + Q + 1];
   } else {
     lane_last<W, NPT, Q + 1, REST...>(c, P, best);

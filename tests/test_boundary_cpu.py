@@ -64,10 +64,11 @@ def test_custom_encoding_bits_and_generic_classification(mpc, configs):
                                                                                 "Cols": [i % 64 for i in range(ts)]})])
     d = mpc.describe_config(cfg)
     assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "unrolled" and d["general_layout"] == "yes"
-    # a root above 15 / a table without a complete first row -> still the fast kernel, through its run-time module loop
+    # a root above 15: no built-in kernel takes it, the general-layout kernel is compiled at creation with the roots as constants
     cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, root=16)])
     d = mpc.describe_config(cfg)
-    assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "run-time loop" and d["general_layout"] == "no"
+    assert d["rc"] == 0 and d["path"] == "fast" and d["sequence"] == "unrolled" and d["compiled"] == "at creation" and d["general_layout"] == "yes"
+    # a table without a complete first row -> still the fast kernel, through its run-time module loop
     for ts, general in ((300, True), (16, True), (12, False)):      # cut inside a bit plane; one complete row; less than a row
         cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, scan={"TableSize": ts, "Rows": [i // 64 for i in range(ts)],
                                                                                     "Cols": [i % 64 for i in range(ts)]})])
@@ -236,5 +237,14 @@ def test_run_time_compilation_of_a_module_sequence_builds_for_gfx950(mpc, config
     # built in / run-time loop: nothing to compile
     assert mpc.describe_config(configs.probe_config(64))["compiled"] == "built in"
     assert mpc.jit_compile_check(configs.probe_config(64)) == 0
+    # a root above 15 (compiled with the roots as constants) and the byte-major order (its own stages) have no built-in kernel at all
     cfg = configs.make_config(64, [az, configs.one_base(64, root=40), configs.consecutive_base(64, 0, True)])
+    assert mpc.describe_config(cfg)["compiled"] == "at creation" and mpc.jit_compile_check(cfg) > 10000
+    bm = {"TableSize": 512, "Rows": [i % 8 for i in range(512)], "Cols": [i // 8 for i in range(512)]}
+    cfg = configs.make_config(64, [az, configs.one_base(64, 0, True, bm), configs.consecutive_base(64, 0, True, bm)])
+    assert mpc.describe_config(cfg)["compiled"] == "at creation" and mpc.jit_compile_check(cfg) > 10000
+    # nothing to compile: a byte-major table with a non-zero root, more than 8 prediction modules
+    cfg = configs.make_config(64, [az, configs.one_base(64, 3, True, bm), configs.consecutive_base(64, 0, True, bm)])
+    assert mpc.describe_config(cfg)["sequence"] == "run-time loop" and mpc.jit_compile_check(cfg) == 0
+    cfg = configs.make_config(64, [az] + [configs.one_base(64, 0, bool(i & 1)) for i in range(9)])
     assert mpc.describe_config(cfg)["sequence"] == "run-time loop" and mpc.jit_compile_check(cfg) == 0

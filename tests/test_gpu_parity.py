@@ -311,8 +311,16 @@ def test_vpc_general_layout_twins(mpc, oracle, configs, traces, L):
     # tables cut inside a bit plane (per-word masks), down to a single complete row
     for roots, ts in (((0, 0, 0), 6 * L + 8), ((6, 2, 1), 4 * L + 7), ((0, 0, 0), 8 * L - 24), ((0, 3, 0), 16), ((9, 0, 0), L + 20)):
         check(probe(roots, ts), True, 5000)
-    # outside the twins' reach: the run-time loop
-    check(probe((16, 0, 0), None), False, 3000)
+    # a root above 15: no built-in twin takes it; the general-layout kernel is compiled at creation with the roots as constants
+    # (the rotation then reaches beyond row 0, and the prefilter drops natural byte 15 for the raw root)
+    for roots, ts in (((16, 0, 0), None), ((L - 1, 17, L // 2 + 1), None), ((5, 20, 0), 6 * L), ((19, L - 2, 16), 4 * L + 7)):
+        cfg = probe(roots, ts)
+        assert mpc.describe_config(cfg)["compiled"] == "at creation"
+        check(cfg, True, 5000)
+        ev = mpc.VPC(cfg)
+        assert ev.kernel_form.startswith("unrolled, compiled at creation"), ev.kernel_form
+        ev.close()
+    # outside the unrolled kernels' reach: the run-time loop
     check(probe((0, 0, 0), 8), False, 3000)
 
 

@@ -15,6 +15,7 @@ cfgs = {
     "probe (unrolled)": C.probe_config(L),
     "mpc_config (5 models)": C.mpc_config(L),
     "probe, roots 5/0/3/2": C.make_config(L, [az, aws, C.one_base(L, 5, True), C.consecutive_base(L, 0, True), C.diff_base(L, prev4, d1, 3, False), C.weight_base(L, prev4, w2, 2, True)]),
+    "probe, roots 40/0/17/33": C.make_config(L, [az, aws, C.one_base(L, 40, True), C.consecutive_base(L, 0, True), C.diff_base(L, prev4, d1, 17, False), C.weight_base(L, prev4, w2, 33, True)]),
     "probe, TableSize 6L": C.make_config(L, [az, aws, C.one_base(L, 0, True, trunc(6 * L)), C.consecutive_base(L, 0, True, trunc(6 * L)), C.diff_base(L, prev4, d1, 0, False, trunc(6 * L)), C.weight_base(L, prev4, w2, 0, True, trunc(6 * L))]),
     "int32 model alone": C.datatype_config(L, "int32"),
     "probe, byte-major scan": C.make_config(L, [az, aws] + [f(*a, {"TableSize": 8 * L, "Rows": [i % 8 for i in range(8 * L)], "Cols": [i // 8 for i in range(8 * L)]})
