@@ -438,11 +438,14 @@ def main():
         torch.cuda.synchronize()
         layouts = [time_layout(torch, mpc, buf, stream, local_rank, name, cfg, n, L) for name, cfg in layout_configs(configs, L)]
         # the paper figure's five data-type models (Bool/INT8, INT16, INT32/64, FP32, FP64: configs.mpc_config) at the figure's
-        # 32-byte block size and at 64 bytes, on the same random words
+        # 32-byte block size, at 64 and at 128 bytes (there its histogram leaves no room for the built-in kernel's rings: compiled at
+        # creation for a smaller workgroup), on the same random words
         layouts.append(time_layout(torch, mpc, buf, stream, local_rank, "the paper figure's five models (configs.mpc_config), 32 B blocks",
                                    configs.mpc_config(32), n * L // 32, 32))
         layouts.append(time_layout(torch, mpc, buf, stream, local_rank, "the paper figure's five models (configs.mpc_config), 64 B blocks",
                                    configs.mpc_config(64), n, 64))
+        layouts.append(time_layout(torch, mpc, buf, stream, local_rank, "the paper figure's five models (configs.mpc_config), 128 B blocks",
+                                   configs.mpc_config(128), n * L // 128, 128))
     # N > 1: BASELINE config 4 -- mixed int/fp blocks sharded contiguously over the ranks, one RCCL
     # all-reduce of the statistics per pass -- as its own sub-record next to the primary value (which
     # stays on the N = 1 workload so that the scaling curve is comparable).

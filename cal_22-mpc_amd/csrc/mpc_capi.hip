@@ -191,7 +191,7 @@ int create_vpc_from_text(const std::string &text, int device, mpc_handle **out)
                      mpcjit::kinds_of(h->plan.params).c_str(), why.c_str());
     }
     // the statistics accumulators of a workgroup live in LDS
-    const size_t smem = h->jit.mod ? mpc_vpc_lane_ring_plan(&h->plan.params, nullptr)
+    const size_t smem = h->jit.mod ? mpc_vpc_lane_ring_plan(&h->plan.params, nullptr, nullptr)
                         : h->plan.fast ? mpc_vpc_lane_smem(&h->plan.params) : mpc_vpc_generic_smem(&h->plan.params);
     if (smem > 160 * 1024) {
       g_create_error = "histogram does not fit the 160 KiB LDS (too many clusters x bins)";
@@ -672,7 +672,7 @@ long long mpc_jit_compile_check(const char *json_text, char *log, size_t cap)
     mpc::build_vpc_plan(cfg, plan);
     if (!mpcjit::eligible(plan.params, plan.fast)) return 0;
     unsigned ring_cfg = 0;
-    const size_t smem = mpc_vpc_lane_ring_plan(&plan.params, &ring_cfg);
+    const size_t smem = mpc_vpc_lane_ring_plan(&plan.params, &ring_cfg, nullptr);
     std::string code;
     if (mpcjit::compile(mpcjit::source_of(plan.params, smem, MPC_TESTING), "gfx950", mpcjit::source_dir(), code, err)) return (long long)code.size();
     rc = MPC_E_HIP;

@@ -42,7 +42,7 @@
 
 #include "mpc_device.h"
 
-extern "C" size_t mpc_vpc_lane_ring_plan(const MpcVpcParams *P, unsigned *ring_cfg);
+extern "C" size_t mpc_vpc_lane_ring_plan(const MpcVpcParams *P, unsigned *ring_cfg, int *wpb);
 extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P);
 
 namespace mpcjit {
@@ -90,7 +90,7 @@ inline bool eligible(const MpcVpcParams &P, bool fast)
   if (!(P.L == 32 || P.L == 64 || P.L == 128)) return false;
   if (mpc_vpc_lane_unrolled(&P)) return false;            // built in (never the byte-major order)
   unsigned ring_cfg = 0;
-  return mpc_vpc_lane_ring_plan(&P, &ring_cfg) != 0;       // the rings fit beside the histogram
+  return mpc_vpc_lane_ring_plan(&P, &ring_cfg, nullptr) != 0;       // the rings fit beside the histogram (with some workgroup size)
 }
 
 namespace detail {
@@ -180,6 +180,8 @@ inline Rtc &rtc()
 inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testing)
 {
   const int W = P.L / 4;
+  int wpb = 0;
+  (void)mpc_vpc_lane_ring_plan(&P, nullptr, &wpb);
   const std::string targs = std::to_string(W) + ", OUT_, " + (P.gen_layout ? "true" : "false") + ", " + kinds_of(P);
   std::ostringstream s;
   s << "#define MPC_LANE_JIT 1\n"
@@ -187,6 +189,7 @@ inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testi
     << "#define MPC_JIT_ANYROOT " << (P.anyroot_unrolled ? 1 : 0) << "\n"
     << "#define MPC_JIT_ROOTS " << roots_of(P) << "\n"
     << "#define MPC_TESTING " << testing << "\n"
+    << "#define " << (P.L <= 32 ? "MPC_LANE_WAVES_32 " : P.L <= 64 ? "MPC_LANE_WAVES " : "MPC_LANE_WAVES_128 ") << wpb << "      /* waves per workgroup of the LDS plan */\n"
     << "#include \"mpc_vpc_lane.hip\"\n"
     << "#define MPC_JIT_KERNEL(NAME, OUT_) \\\n"
     << "extern \"C\" __global__ void MPC_LANE_BOUNDS(" << W << ", " << P.n_pred << ") \\\n"
@@ -315,7 +318,7 @@ inline bool compile(const std::string &source, const std::string &arch, const st
 inline bool build(const MpcVpcParams &P, int testing, Kernels &out, std::string &why)
 {
   unsigned ring_cfg = 0;
-  const size_t smem = mpc_vpc_lane_ring_plan(&P, &ring_cfg);
+  const size_t smem = mpc_vpc_lane_ring_plan(&P, &ring_cfg, nullptr);
   if (smem == 0) { why = "the line rings do not fit the LDS beside the histogram"; return false; }
   const std::string src_dir = source_dir();
   std::string all_sources;

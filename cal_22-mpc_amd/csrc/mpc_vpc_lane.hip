@@ -1515,11 +1515,21 @@ extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P)
 
 // LDS plan of an unrolled launch, whether or not the sequence is built in: bytes (0: the rings do not fit beside the
 // histogram) and the kernels' ring_cfg argument.  (mpc_jit.h: the size of a run-time compiled kernel's static LDS array.)
-extern "C" size_t mpc_vpc_lane_ring_plan(const MpcVpcParams *P, unsigned *ring_cfg)
+// wpb: the waves per workgroup of the plan -- the built-in kernels' (16 / 16 / 8 for 32- / 64- / 128-byte lines) when the rings
+// fit beside the histogram with that many waves, else the largest smaller workgroup they fit with (many clusters: the paper
+// figure's five models at 128-byte lines miss by 1 KiB with 8 waves): only a kernel compiled at creation can have that size.
+extern "C" size_t mpc_vpc_lane_ring_plan(const MpcVpcParams *P, unsigned *ring_cfg, int *wpb)
 {
-  const LaneLds plan = lane_lds_plan(P, lane_wpb_of(P->L), P->L <= 64);
-  if (ring_cfg) *ring_cfg = plan.stages | (plan.cap << 8);
-  return plan.stages == 0 ? 0 : plan.bytes;
+  const int full = lane_wpb_of(P->L);
+  const int cand[5] = {full, full * 7 / 8, full * 3 / 4, full * 5 / 8, full / 2};
+  for (int w : cand) {
+    const LaneLds plan = lane_lds_plan(P, w, P->L <= 64);
+    if (plan.stages == 0) continue;
+    if (ring_cfg) *ring_cfg = plan.stages | (plan.cap << 8);
+    if (wpb) *wpb = w;
+    return plan.bytes;
+  }
+  return 0;
 }
 
 // Launch of a run-time compiled sequence (mpc_jit.h): the grid and the kernel arguments of lane_launch, through the
@@ -1529,8 +1539,8 @@ extern "C" hipError_t mpc_launch_vpc_lane_jit(hipFunction_t fn_stats, hipFunctio
                                               hipStream_t stream)
 {
   unsigned ring_cfg = 0;
-  if (mpc_vpc_lane_ring_plan(P, &ring_cfg) == 0) return hipErrorInvalidConfiguration;
-  const int wpb = lane_wpb_of(P->L);
+  int wpb = 0;
+  if (mpc_vpc_lane_ring_plan(P, &ring_cfg, &wpb) == 0) return hipErrorInvalidConfiguration;
   const u64 max_lines = 1ull << 30;     // 32-bit line indices inside the kernel
   hipFunction_t fn = (d_sizes || d_sel) ? fn_lines : fn_stats;
   for (u64 done = 0; done < n_lines; done += max_lines) {
@@ -1539,7 +1549,7 @@ extern "C" hipError_t mpc_launch_vpc_lane_jit(hipFunction_t fn_stats, hipFunctio
     u32 n32 = (u32)take;
     u64 first_line = done;
     const u64 want = (take / 64u + (u64)wpb - 1u) / (u64)wpb;
-    const u64 cap = (u64)grid / (wpb == 16 ? 16u : 8u);
+    const u64 cap = (u64)grid / (wpb > 8 ? 16u : 8u);
     int wgrid = (int)(want < cap ? want : cap);
     if (wgrid < 1) wgrid = 1;
     MpcVpcParams params = *P;

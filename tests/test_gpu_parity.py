@@ -375,11 +375,8 @@ def test_vpc_sequences_compiled_at_creation(mpc, oracle, configs, traces, L, tmp
     for name, make in seqs.items():
         for ts, roots in ((None, (0, 0, 0)), (6 * L, (5, 3, 2))):          # plain layout, general layout
             cfg = configs.make_config(L, make(trunc(ts), roots))
-            if L == 128 and name == "8 modules":
-                # 11 clusters x 1030 bins: the histogram leaves no room for the line rings, nothing is compiled
-                assert mpc.describe_config(cfg)["sequence"] == "run-time loop"
-                run(cfg, "run-time loop")
-                continue
+            # (128-byte lines, 8 modules: 11 clusters x 1030 bins leave no room for the rings of 8 waves -- the kernel is compiled
+            # for a smaller workgroup, mpc_vpc_lane_ring_plan)
             d = mpc.describe_config(cfg)
             assert d["sequence"] == "unrolled" and d["compiled"] == "at creation" and d["general_layout"] == ("yes" if ts else "no"), (name, d)
             first = run(cfg, "unrolled, compiled at creation")
@@ -404,6 +401,11 @@ def test_vpc_sequences_compiled_at_creation(mpc, oracle, configs, traces, L, tmp
     run(configs.make_config(L, [az, aws, configs.consecutive_base(L, 0, True, sb)]), "unrolled, compiled at creation")
     run(configs.make_config(L, [az, aws, configs.one_base(L, 6, True, sb), configs.consecutive_base(L, 0, False, sb)]), "run-time loop")
     run(configs.make_config(L, [az, aws, configs.one_base(L, 0, True, bytemajor(8)), configs.consecutive_base(L, 0, False, bytemajor(8))]), "run-time loop")
+    # the paper figure's five models: a built-in sequence, but at 128-byte lines its 8 clusters x 1029 bins leave 1 KiB too
+    # little for the rings of the built-in 8-wave workgroup -- compiled at creation for 7 waves instead of the run-time loop
+    cfg5 = configs.mpc_config(L)
+    assert mpc.describe_config(cfg5)["compiled"] == ("at creation" if L == 128 else "built in")
+    run(cfg5, "unrolled, compiled at creation" if L == 128 else "unrolled")
     # switched off: the run-time module loop, same results
     monkeypatch.setenv("MPC_JIT", "0")
     cfg = configs.make_config(L, seqs["OB DF WT OB"](None, (0, 0, 0)))
