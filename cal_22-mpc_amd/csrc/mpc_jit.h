@@ -16,6 +16,7 @@
 //   MPC_JIT=0            never compile at run time
 //   MPC_JITC=PATH        the helper program (default: mpc_jitc next to the library; without one hiprtc is dlopen'ed here)
 //   MPC_JIT_SRC=DIR      the kernel sources (default: <directory of libmpc_hip*.so>/csrc)
+//   MPC_JIT_MAX_MODULES=N  longest module sequence that is compiled (default 12, at most 16)
 //   MPC_JIT_DEBUG=1      say on stderr where the compilation ran
 //   MPC_JIT_CACHE=DIR    code object cache (default: $XDG_CACHE_HOME/mpc_hip or ~/.cache/mpc_hip); "" = no cache
 #pragma once
@@ -47,7 +48,15 @@ extern "C" int mpc_vpc_lane_unrolled(const MpcVpcParams *P);
 
 namespace mpcjit {
 
-constexpr int kMaxModules = 8;      // longer sequences stay on the run-time loop (code size, compile time)
+// Sequences of more than 12 prediction modules stay on the run-time loop (MPC_JIT_MAX_MODULES overrides, up to 16): the
+// unrolled code still wins there (tools/dev/seq_len.py: 12 modules 0.42 against 0.22 of the peak on random data, 14 modules
+// 0.34 against 0.19) but spills more and more registers (84 VGPRs at 12 modules) and takes longer to compile.
+inline int max_modules()
+{
+  const char *e = std::getenv("MPC_JIT_MAX_MODULES");
+  const int v = e ? std::atoi(e) : 12;
+  return v < 1 ? 1 : (v > 16 ? 16 : v);
+}
 
 struct Kernels {
   hipModule_t mod = nullptr;
@@ -86,7 +95,7 @@ inline bool eligible(const MpcVpcParams &P, bool fast)
 {
   const char *env = std::getenv("MPC_JIT");
   if (env && std::strcmp(env, "0") == 0) return false;
-  if (!fast || (P.runtime_only && !P.bm_unrolled && !P.anyroot_unrolled) || P.n_pred < 1 || P.n_pred > kMaxModules) return false;
+  if (!fast || (P.runtime_only && !P.bm_unrolled && !P.anyroot_unrolled) || P.n_pred < 1 || P.n_pred > max_modules()) return false;
   if (!(P.L == 32 || P.L == 64 || P.L == 128)) return false;
   if (mpc_vpc_lane_unrolled(&P)) return false;            // built in (never the byte-major order)
   unsigned ring_cfg = 0;

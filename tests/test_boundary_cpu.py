@@ -243,8 +243,8 @@ def test_run_time_compilation_of_a_module_sequence_builds_for_gfx950(mpc, config
     bm = {"TableSize": 512, "Rows": [i % 8 for i in range(512)], "Cols": [i // 8 for i in range(512)]}
     cfg = configs.make_config(64, [az, configs.one_base(64, 0, True, bm), configs.consecutive_base(64, 0, True, bm)])
     assert mpc.describe_config(cfg)["compiled"] == "at creation" and mpc.jit_compile_check(cfg) > 10000
-    # nothing to compile: a byte-major table with a non-zero root, more than 8 prediction modules
+    # nothing to compile: a byte-major table with a non-zero root, more than 12 prediction modules
     cfg = configs.make_config(64, [az, configs.one_base(64, 3, True, bm), configs.consecutive_base(64, 0, True, bm)])
     assert mpc.describe_config(cfg)["sequence"] == "run-time loop" and mpc.jit_compile_check(cfg) == 0
-    cfg = configs.make_config(64, [az] + [configs.one_base(64, 0, bool(i & 1)) for i in range(9)])
+    cfg = configs.make_config(64, [az] + [configs.one_base(64, 0, bool(i & 1)) for i in range(13)])
     assert mpc.describe_config(cfg)["sequence"] == "run-time loop" and mpc.jit_compile_check(cfg) == 0

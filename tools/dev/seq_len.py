@@ -8,14 +8,15 @@ L = 64; n = (4 << 30) // L
 az, aws = {"name": "AllZero"}, {"name": "AllWordSame"}
 prev1 = [max(i - 1, 0) for i in range(L)]; prev4 = [max(i - 4, 0) for i in range(L)]; prev8 = [max(i - 8, 0) for i in range(L)]
 w2 = [[1.0, 0.5][i % 2] for i in range(L)]; diff = [(-2 + (i % 5)) for i in range(L)]
-pool = [C.diff_base(L, prev8, [1] * L, 0, True), C.one_base(L, 0, False), C.consecutive_base(L, 0, False), C.weight_base(L, prev8, w2, 0, True),
+os.environ["MPC_JIT_MAX_MODULES"] = "16"
+pool = 2 * [C.diff_base(L, prev8, [1] * L, 0, True), C.one_base(L, 0, False), C.consecutive_base(L, 0, False), C.weight_base(L, prev8, w2, 0, True),
         C.diff_base(L, prev4, diff, 0, False), C.weight_base(L, prev1, w2, 0, False), C.one_base(L, 0, True), C.consecutive_base(L, 0, True)]
 st = torch.cuda.Stream()
 os.environ["MPC_JIT_CACHE"] = ""
 for wl in ("random_u32", "mixed"):
     buf = torch.empty(n * L, dtype=torch.uint8, device="cuda:0")
     mpc.synth_fill(buf.data_ptr(), n, L, wl); torch.cuda.synchronize()
-    for k in (3, 5, 6, 7, 8):
+    for k in (3, 5, 8, 10, 12, 14):
         cfg = C.make_config(L, [az, aws] + pool[:k])
         out = []
         for jit in ("1", "0"):
