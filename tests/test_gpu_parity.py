@@ -401,6 +401,11 @@ def test_vpc_sequences_compiled_at_creation(mpc, oracle, configs, traces, L, tmp
     run(configs.make_config(L, [az, aws, configs.consecutive_base(L, 0, True, sb)]), "unrolled, compiled at creation")
     run(configs.make_config(L, [az, aws, configs.one_base(L, 6, True, sb), configs.consecutive_base(L, 0, False, sb)]), "run-time loop")
     run(configs.make_config(L, [az, aws, configs.one_base(L, 0, True, bytemajor(8)), configs.consecutive_base(L, 0, False, bytemajor(8))]), "run-time loop")
+    if L == 64:      # the longest sequence that is compiled (12 prediction modules; the kernel spills registers but beats the loop)
+        twelve = seqs["8 modules"](None, (0, 0, 0)) + [configs.one_base(L, 0, False), configs.diff_base(L, prev1, diff, 0, True),
+                                                        configs.weight_base(L, prev4, w2, 0, False), configs.consecutive_base(L, 0, True)]
+        run(configs.make_config(L, twelve), "unrolled, compiled at creation")
+        run(configs.make_config(L, twelve + [configs.one_base(L, 0, True)]), "run-time loop")
     # the paper figure's five models: a built-in sequence, but at 128-byte lines its 8 clusters x 1029 bins leave 1 KiB too
     # little for the rings of the built-in 8-wave workgroup -- compiled at creation for 7 waves instead of the run-time loop
     cfg5 = configs.mpc_config(L)
