@@ -187,8 +187,14 @@ int create_vpc_from_text(const std::string &text, int device, mpc_handle **out)
       std::string why;
       (void)hipSetDevice(h->device);
       if (!mpcjit::build(h->plan.params, MPC_TESTING, h->jit, why))
-        std::fprintf(stderr, "libmpc_hip: module sequence [%s] runs the run-time module loop (several times slower): %s\n",
-                     mpcjit::kinds_of(h->plan.params).c_str(), why.c_str());
+        std::fprintf(stderr, "libmpc_hip: module sequence [%s] runs the %s: %s\n", mpcjit::kinds_of(h->plan.params).c_str(),
+                     h->plan.params.planes_differ ? "generic kernel (some hundred times slower)" : "run-time module loop (several times slower)",
+                     why.c_str());
+    }
+    if (h->plan.fast && h->plan.params.planes_differ && !h->jit.mod) {
+      // scan tables of different sizes: only a kernel compiled at creation evaluates them on the fast path
+      h->plan.fast = false;
+      h->plan.why_generic = "scan tables of different sizes, and the kernel for them could not be compiled at creation";
     }
     // the statistics accumulators of a workgroup live in LDS
     const size_t smem = h->jit.mod ? mpc_vpc_lane_ring_plan(&h->plan.params, nullptr, nullptr)
@@ -1016,6 +1022,10 @@ int mpc_config_describe(const char *json_text, char *out, size_t cap)
   } else {
     mpc::VpcPlan plan;
     mpc::build_vpc_plan(cfg, plan);
+    if (plan.fast && plan.params.planes_differ && !mpcjit::eligible(plan.params, true)) {      // (as mpc_create_vpc* decides)
+      plan.fast = false;
+      plan.why_generic = "scan tables of different sizes, and run-time compilation is not available for them";
+    }
     s = "{\"L\": " + std::to_string(cfg.L) + ", \"M\": " + std::to_string(cfg.M) + ", \"n_pred\": " + std::to_string(cfg.n_pred) +
         ", \"has_aws\": " + (cfg.has_aws ? "true" : "false") + ", \"hist_bins\": " + std::to_string(cfg.hist_bins) + ", \"enc_bits\": [";
     for (size_t i = 0; i < cfg.enc_bits.size(); i++) s += (i ? ", " : "") + std::to_string(cfg.enc_bits[i]);

@@ -282,7 +282,12 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
       no(tag + "scan table is neither a (truncated) plane-major nor a (truncated) byte-major identity, or the modules differ");
       break;
     }
-    if (m.table_size != m0.table_size) { no(tag + "scan tables of different sizes"); break; }
+    if (m.table_size != m0.table_size) {
+      // different sizes: only when every plane-major table stops after a whole number of bit planes (a per-module mask)
+      auto whole = [&](const Module &x) { return x.table_size == 8 * L || (x.table_size >= L && x.table_size % L == 0); };
+      if (bm0 || !whole(m) || !whole(m0)) { no(tag + "scan tables of different sizes"); break; }
+      P.planes_differ = 1;
+    }
     P.byte_major = bm0 ? 1 : 0;
     if (bm0) P.runtime_only = 1;
     // any root for OneBase / DiffBase / WeightBase: the residue array is the natural one with bytes 0..root
@@ -296,6 +301,7 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
       else P.runtime_only = 1;
     }
     f.cx = m.consecutive_xor ? 1 : 0;
+    f.plane_mask = (bm0 || m.table_size >= 8 * L || m.table_size < L) ? ~0u : ((0xff00u >> (m.table_size / L)) & 0xffu) * 0x01010101u;
     f.tab_off = (int32_t)plan.tab.size();
     if (m.pred_kind == PRED_ONEBASE) { f.kind = MPC_FK_ONEBASE; continue; }
     if (m.pred_kind == PRED_CONSEC) { f.kind = MPC_FK_CONSEC; continue; }
@@ -379,6 +385,17 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     }
   }
   if (P.runtime_only) P.gen_layout = 0;
+  if (plan.fast && P.planes_differ) {
+    bool roots_ok = true;
+    for (int q = 0; q < cfg.n_pred; q++) roots_ok = roots_ok && P.fm[q].root <= 15;
+    if (!roots_ok) {
+      plan.fast = false;
+      plan.why_generic = "scan tables of different sizes together with a RootIndex above 15";
+    } else {
+      P.runtime_only = 1;        // no built-in kernel, and not the run-time loop either (one mask for all modules there)
+      P.gen_layout = 1;
+    }
+  }
   if (plan.fast && !P.byte_major && cfg.n_pred > 0 && cfg.modules[(size_t)cfg.start].table_size >= 16) {
     bool far_root = false;
     for (int q = 0; q < cfg.n_pred; q++) far_root = far_root || P.fm[q].root > 15;
@@ -397,12 +414,12 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     }
   }
   P.plane_mask = ~0u;
-  if (plan.fast && cfg.n_pred > 0 && !P.byte_major) {
+  if (plan.fast && cfg.n_pred > 0 && !P.byte_major && !P.planes_differ) {
     const int ts = cfg.modules[(size_t)cfg.start].table_size;
     if (ts >= L && ts % L == 0 && ts < 8 * L) P.plane_mask = ((0xff00u >> (ts / L)) & 0xffu) * 0x01010101u;
   }
   P.trunc_off = -1;
-  if (plan.fast && cfg.n_pred > 0 && cfg.modules[(size_t)cfg.start].table_size != 8 * L) {
+  if (plan.fast && !P.planes_differ && cfg.n_pred > 0 && cfg.modules[(size_t)cfg.start].table_size != 8 * L) {
     // scanned bit i = plane i / L (0 = MSB), byte i % L, for i < TableSize: per residue byte the mask of its scanned bits
     const int ts = cfg.modules[(size_t)cfg.start].table_size;
     while (plan.tab.size() % 4) plan.tab.push_back(0);

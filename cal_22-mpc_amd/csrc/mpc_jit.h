@@ -95,7 +95,7 @@ inline bool eligible(const MpcVpcParams &P, bool fast)
 {
   const char *env = std::getenv("MPC_JIT");
   if (env && std::strcmp(env, "0") == 0) return false;
-  if (!fast || (P.runtime_only && !P.bm_unrolled && !P.anyroot_unrolled) || P.n_pred < 1 || P.n_pred > max_modules()) return false;
+  if (!fast || (P.runtime_only && !P.bm_unrolled && !P.anyroot_unrolled && !P.planes_differ) || P.n_pred < 1 || P.n_pred > max_modules()) return false;
   if (!(P.L == 32 || P.L == 64 || P.L == 128)) return false;
   if (mpc_vpc_lane_unrolled(&P)) return false;            // built in (never the byte-major order)
   unsigned ring_cfg = 0;
@@ -196,6 +196,7 @@ inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testi
   s << "#define MPC_LANE_JIT 1\n"
     << "#define MPC_JIT_BM " << (P.bm_unrolled ? 1 : 0) << "\n"
     << "#define MPC_JIT_ANYROOT " << (P.anyroot_unrolled ? 1 : 0) << "\n"
+    << "#define MPC_JIT_PLANES " << (P.planes_differ ? 1 : 0) << "\n"
     << "#define MPC_JIT_ROOTS " << roots_of(P) << "\n"
     << "#define MPC_TESTING " << testing << "\n"
     << "#define " << (P.L <= 32 ? "MPC_LANE_WAVES_32 " : P.L <= 64 ? "MPC_LANE_WAVES " : "MPC_LANE_WAVES_128 ") << wpb << "      /* waves per workgroup of the LDS plan */\n"

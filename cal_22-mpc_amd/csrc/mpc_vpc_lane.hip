@@ -45,6 +45,12 @@
 #ifndef MPC_JIT_ANYROOT
 #define MPC_JIT_ANYROOT 0
 #endif
+// 1 only in a translation unit that mpc_jit.h compiles for a configuration whose plane-major tables stop after a whole number
+// of bit planes that DIFFERS between the modules: the selector takes each module's own mask (MpcFastModule::plane_mask) and the
+// winner's mask travels with it to the XOR stage.
+#ifndef MPC_JIT_PLANES
+#define MPC_JIT_PLANES 0
+#endif
 #ifndef MPC_ABLATE
 #define MPC_ABLATE 0   // development-only timing ablations (tools/ablate.sh); results are WRONG when non-zero
 #endif
@@ -308,6 +314,7 @@ struct LaneBest {
   int q;
   u32 root_r;
   u32 cx;
+  u32 pm;      // MPC_JIT_PLANES: the winner's scanned bit planes
   u32 encb;    // id bits of the winner's cluster (wave-uniform scalar loads, selected per lane: an
                // indexed read of the kernel arguments per lane would be a vector load + full wait)
 };
@@ -432,14 +439,16 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
     u32 r[W], root_r;
     lane_residue<W, KIND>(c, LANE_FM(Q), lane_tab(P), r, root_r);
     if (c.gen && LANE_FM(Q).root != 0) lane_root_to_front<W, W>(c, LANE_FM(Q).root, r);
+    const u32 pm_q = MPC_JIT_PLANES ? LANE_FM(Q).plane_mask : (c.gen ? P.plane_mask : ~0u);
     const u32 z = MPC_JIT_BM ? lane_leading_zero_rows_bm<W, W>(r, c.gen ? c.trunc : nullptr, 2u * W)
-                             : lane_leading_zero_rows<W>(r, c.gen ? c.trunc : nullptr, c.gen ? P.plane_mask : ~0u);
+                             : lane_leading_zero_rows<W>(r, c.gen ? c.trunc : nullptr, pm_q);
     if (!any_full) {
       // the first module evaluated for the group (wave-uniform): it is the winner so far, nothing to select
       best.z = z;
       best.q = Q;
       best.root_r = root_r;
       best.cx = (u32)LANE_FM(Q).cx;
+      best.pm = pm_q;
       best.encb = (u32)P.enc_bits[P.start + Q + 1];
 #pragma unroll
       for (int e = 0; e < W; e++) best.r[e] = r[e];
@@ -450,6 +459,7 @@ __device__ __forceinline__ void lane_seq(const Lane<W> &c, const MpcVpcParams &P
       best.q = (int)mask_sel(m, (u32)Q, (u32)best.q);
       best.root_r = mask_sel(m, root_r, best.root_r);
       best.cx = mask_sel(m, (u32)LANE_FM(Q).cx, best.cx);
+      if (MPC_JIT_PLANES) best.pm = mask_sel(m, pm_q, best.pm);
       best.encb = mask_sel(m, (u32)P.enc_bits[P.start + Q + 1], best.encb);
 #pragma unroll
       for (int e = 0; e < W; e++) best.r[e] = mask_sel(m, r[e], best.r[e]);
@@ -471,6 +481,7 @@ __device__ __forceinline__ void lane_last(const Lane<W> &c, const MpcVpcParams &
     if (c.gen && LANE_FM(Q).root != 0) lane_root_to_front<W, W>(c, LANE_FM(Q).root, best.r);
     best.q = Q;
     best.cx = (u32)LANE_FM(Q).cx;
+    best.pm = MPC_JIT_PLANES ? LANE_FM(Q).plane_mask : ~0u;
     best.encb = (u32)P.enc_bits[P.start + Q + 1];
   } else {
     lane_last<W, NPT, Q + 1, REST...>(c, P, best);
@@ -983,6 +994,10 @@ __device__ __forceinline__ void lane_step(const uint4 (&v)[W / 4], u32 line0, u3
     if ((NPT == 0 || GEN) && scan_mask) {      // (wave-uniform) a table cut inside a bit plane: per-word masks
 #pragma unroll
       for (int e = 0; e < W; e++) t[e] &= scan_mask[e];
+    }
+    if (MPC_JIT_PLANES && NPT > 0) {       // each module its own number of bit planes: the winner's
+#pragma unroll
+      for (int e = 0; e < W; e++) t[e] &= best.pm;
     }
     if (GEN && P.plane_mask != ~0u) {      // (wave-uniform) a table that stops after whole bit planes: the others are not scanned
 #pragma unroll

@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI of include/mpc_hip.h) against the
 CPU oracle on the same inputs -- bit-exact per-line sizes, selected clusters and
 the full integer statistics vector.  Runs on the MI355X box (`-m gpu`)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -254,8 +256,18 @@ def test_vpc_fast_path_nonzero_root_and_truncated_scan(mpc, oracle, configs, tra
     # both at once; and tables of different sizes have no fast form
     mods = [az, configs.diff_base(L, prev1, diff, 5, True, trunc(5 * L)), configs.weight_base(L, prev4, w2, 2, False, trunc(5 * L))]
     _check_vpc(mpc, oracle, configs.make_config(L, mods), lines, expect_path=mpc.MPC_PATH_VPC_FAST)
+    # tables of different sizes: whole bit planes per module are compiled at creation (a mask per module); any other mix has no fast form
     mods = [az, configs.one_base(L, 0, True, trunc(5 * L)), configs.one_base(L, 0, False, trunc(6 * L))]
+    _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:1500], expect_path=mpc.MPC_PATH_VPC_FAST)
+    mods = [az, configs.one_base(L, 0, True, trunc(5 * L)), configs.one_base(L, 0, False, trunc(6 * L + 3))]
     _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:1500], expect_path=mpc.MPC_PATH_VPC_GENERIC)
+    os.environ["MPC_JIT"] = "0"                  # without the run-time compiler the different whole-plane sizes take the generic kernel
+    try:
+        mods = [az, configs.one_base(L, 0, True, trunc(5 * L)), configs.one_base(L, 0, False, trunc(6 * L))]
+        assert mpc.describe_config(configs.make_config(L, mods))["path"] == "generic"
+        _check_vpc(mpc, oracle, configs.make_config(L, mods), lines[:1500], expect_path=mpc.MPC_PATH_VPC_GENERIC)
+    finally:
+        del os.environ["MPC_JIT"]
 
 
 @pytest.mark.parametrize("L", [32, 64, 128])
@@ -320,6 +332,15 @@ def test_vpc_general_layout_twins(mpc, oracle, configs, traces, L):
         ev = mpc.VPC(cfg)
         assert ev.kernel_form.startswith("unrolled, compiled at creation"), ev.kernel_form
         ev.close()
+    # every module its own number of bit planes (no built-in kernel, not the run-time loop either: compiled at creation with a
+    # mask per module; the winner's mask goes with it to the XOR stage) -- round 2 ran these on the generic kernel
+    for sizes, roots in (((8, 6, 4, 7), (0, 3, 0)), ((3, 8, 8, 1), (5, 0, 2)), ((8, 8, 8, 2), (0, 0, 0))):
+        mods = [az, aws, configs.one_base(L, roots[0], True, trunc(sizes[0] * L)), configs.consecutive_base(L, 0, True, trunc(sizes[1] * L)),
+                configs.diff_base(L, prev4, d1, roots[1], False, trunc(sizes[2] * L)), configs.weight_base(L, prev4, w2, roots[2], True, trunc(sizes[3] * L))]
+        cfg = configs.make_config(L, mods)
+        d = mpc.describe_config(cfg)
+        assert d["path"] == "fast" and d["compiled"] == "at creation", d
+        check(cfg, True, 6000)
     # outside the unrolled kernels' reach: the run-time loop
     check(probe((0, 0, 0), 8), False, 3000)
 
