@@ -417,6 +417,14 @@ def main():
     if rank == 0 and args.lines % 4096 == 0:
         check_known_ratio(args.algo, args.workload, L, n, ratio)
 
+    if args.algo == "VPC" and rank == 0:
+        # a full-size property no smaller run can stand in for: the byte sum behind cluster -1's MAE (VPC.cpp:417-443 with r = line[i])
+        # against a sum of the resident buffer computed by torch -- they differ by at most 255 per byte of the lines that went to
+        # another cluster
+        total = int(buf.sum(dtype=torch.int64).item())
+        count_unc, sum_r_unc = int(v[3]) // args.steps, int(v[3 + 4]) // args.steps
+        assert int(v[3]) % args.steps == 0 and int(v[3 + 4]) % args.steps == 0, "every pass counts the same"
+        assert abs(total - sum_r_unc) <= (n - count_unc) * L * 255, (total, sum_r_unc, n - count_unc)
     kernel_name = kernel_label(mpc, ev, args.algo, L)
     power = PowerProbe(torch, local_rank) if (world == 1 and not args.no_workloads) else None      # (not under tools/profile_round.sh)
     headline_power = power.run(torch, lambda: ev.compress_device(buf.data_ptr(), n, stream=sp), stream, 1.5) if power else None
