@@ -243,6 +243,22 @@ def test_run_time_compilation_of_a_module_sequence_builds_for_gfx950(mpc, config
     bm = {"TableSize": 512, "Rows": [i % 8 for i in range(512)], "Cols": [i // 8 for i in range(512)]}
     cfg = configs.make_config(64, [az, configs.one_base(64, 0, True, bm), configs.consecutive_base(64, 0, True, bm)])
     assert mpc.describe_config(cfg)["compiled"] == "at creation" and mpc.jit_compile_check(cfg) > 10000
+    # every variant of the generated translation unit, at the other line sizes too: byte-major (truncated), roots above 15 as
+    # constants, a different number of bit planes per module, a workgroup smaller than the built-in one (the five models at 128 B)
+    for L in (32, 128):
+        def pm(ts):
+            return {"TableSize": ts, "Rows": [i // L for i in range(ts)], "Cols": [i % L for i in range(ts)]}
+        bmL = {"TableSize": 8 * L - 20, "Rows": [i % 8 for i in range(8 * L - 20)], "Cols": [i // 8 for i in range(8 * L - 20)]}
+        prev4 = [max(i - 4, 0) for i in range(L)]
+        w2 = [[1.0, 0.5][i % 2] for i in range(L)]
+        for mods in ([az, configs.one_base(L, 0, True, bmL), configs.weight_base(L, prev4, w2, 0, True, bmL)],
+                     [az, configs.one_base(L, L - 1, True), configs.weight_base(L, prev4, w2, 17, True), configs.consecutive_base(L, 0, False)],
+                     [az, configs.one_base(L, 2, True, pm(6 * L)), configs.consecutive_base(L, 0, True, pm(8 * L)), configs.weight_base(L, prev4, w2, 0, True, pm(3 * L))]):
+            cfg = configs.make_config(L, mods)
+            assert mpc.describe_config(cfg)["compiled"] == "at creation", mpc.describe_config(cfg)
+            assert mpc.jit_compile_check(cfg) > 10000
+    d = mpc.describe_config(configs.mpc_config(128))
+    assert d["sequence"] == "unrolled" and d["compiled"] == "at creation" and mpc.jit_compile_check(configs.mpc_config(128)) > 10000
     # nothing to compile: a byte-major table with a non-zero root, more than 12 prediction modules
     cfg = configs.make_config(64, [az, configs.one_base(64, 3, True, bm), configs.consecutive_base(64, 0, True, bm)])
     assert mpc.describe_config(cfg)["sequence"] == "run-time loop" and mpc.jit_compile_check(cfg) == 0
