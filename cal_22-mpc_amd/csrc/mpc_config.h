@@ -312,6 +312,7 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     int shifts[2] = {0, 0}, nshift = 0;
     bool stride2 = L >= 16 && m.root < 8;       // (words 0 and 1 have table entries of their own)
     for (int i = 8; i < L; i++) stride2 = stride2 && m.base[(size_t)i] == i - 8;
+    bool gather = false;                         // a base byte outside the window: gathered with the table as constants (mpc_jit.h)
     for (int i = 0; i < L && plan.fast; i++) {
       const int w = i / 4, k = i % 4;
       if (i == m.root) { sel[(size_t)w] |= 0x0cu << (8 * k); continue; }  // root: predicted byte forced to 0
@@ -320,12 +321,13 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
       if (stride2 && w >= 2) {
         s = k;                                     // the same byte of the source word (two words back)
       } else if (w == 0) {
-        if (b > 3) { no(tag + "BaseIndexTable is not windowed (own/previous dword)"); break; }
-        s = 4 + b;
+        if (b > 3) gather = true;
+        s = 4 + (b & 3);
       } else {
-        if (b < 4 * (w - 1) || b > 4 * w + 3) { no(tag + "BaseIndexTable is not windowed (own/previous dword)"); break; }
-        s = b - 4 * (w - 1);
+        if (b < 4 * (w - 1) || b > 4 * w + 3) gather = true;
+        s = (b - 4 * (w - 1)) & 7;
       }
+      if (b < 0 || b >= L) { no(tag + "BaseIndexTable entry out of range"); break; }
       sel[(size_t)w] |= (uint32_t)s << (8 * k);
       if (m.pred_kind == PRED_DIFF) {
         c1[(size_t)w] |= (uint32_t)(uint8_t)m.diff[(size_t)i] << (8 * k);
@@ -370,21 +372,39 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     // c1 split into its low-7-bit and MSB parts (lane-per-line kernel, WeightBase residue)
     for (size_t w = 0; w < c1.size(); w++) plan.tab.push_back(c1[w] & 0x7f7f7f7fu);
     for (size_t w = 0; w < c1.size(); w++) plan.tab.push_back(c1[w] & 0x80808080u);
+    if (gather) {
+      f.gather = 1;
+      P.gather_unrolled = 1;
+      stride2 = false;
+    }
     // periodic tables: words 1.. all use "the same byte of the previous word" with identical masks /
     // constants, so the kernel needs neither the byte gather nor per-word table entries
     f.prev_word = 1;
     for (size_t w = 1; w < sel.size(); w++)
-      if (sel[w] != 0x03020100u || c1[w] != c1[1] || c2[w] != c2[1]) f.prev_word = 0;
+      if (gather || sel[w] != 0x03020100u || c1[w] != c1[1] || c2[w] != c2[1]) f.prev_word = 0;
     if (stride2) {
       // two-words-back tables must repeat with the element (2 words) from word 2 on: the kernel
       // has no byte gather for them and reads the entries of words 2 and 3 for even / odd words
       f.prev_word = 2;
       for (size_t w = 4; w < sel.size(); w++)
-        if (c1[w] != c1[2 + (w & 1)] || c2[w] != c2[2 + (w & 1)]) { no(tag + "BaseIndexTable i-8 with constants that do not repeat every 8 bytes"); break; }
-      if (!plan.fast) break;
+        if (c1[w] != c1[2 + (w & 1)] || c2[w] != c2[2 + (w & 1)]) {
+          // constants that do not repeat every 8 bytes: per-word table entries and a byte gather (two words back is outside the window)
+          f.prev_word = 0;
+          f.gather = 1;
+          P.gather_unrolled = 1;
+          break;
+        }
     }
   }
   if (P.runtime_only) P.gen_layout = 0;
+  if (plan.fast && P.gather_unrolled) {
+    if (P.byte_major || P.runtime_only || P.planes_differ) {
+      plan.fast = false;
+      plan.why_generic = "BaseIndexTable is not windowed (own/previous dword), together with another layout the built-in kernels lack";
+    } else {
+      P.runtime_only = 1;        // no built-in kernel, and not the run-time loop either (its byte gather is the windowed one)
+    }
+  }
   if (plan.fast && P.planes_differ) {
     bool roots_ok = true;
     for (int q = 0; q < cfg.n_pred; q++) roots_ok = roots_ok && P.fm[q].root <= 15;

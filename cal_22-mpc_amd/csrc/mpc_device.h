@@ -39,6 +39,8 @@ struct MpcFastModule {
   int32_t tab_off;    /* DIFF/WEIGHT: dword offset of {sel, c1, c2, c1 & 0x7f.., c1 & 0x80..}[L/4 each] in tab */
   int32_t root;       /* RootIndex (0 on the plain unrolled kernels, 0..15 on their general-layout twins; any position for
                          ONEBASE / DIFF / WEIGHT* on the run-time loop) */
+  int32_t gather;     /* DIFF / WEIGHT*: 1 = the BaseIndexTable is not windowed (a base byte outside the own / previous dword): the
+                         base bytes are gathered with the table as compile-time constants (gather_unrolled configurations) */
   uint32_t plane_mask; /* this module's scanned bit planes, in every byte (planes_differ configurations; else unused) */
   int32_t prev_word;  /* DIFF/WEIGHT periodic tables.  1: every base byte of words 1.. is the same byte of the
                          previous word (BaseIndexTable[i] = i - 4) and the table entries of words 1.. are
@@ -91,6 +93,9 @@ struct MpcVpcParams {
   int32_t anyroot_unrolled; /* 1: plane-major order, complete first row, some RootIndex above 15: no built-in kernel (runtime_only
                            stays 1), but the general-layout kernels can be compiled for it at handle creation with the roots as
                            constants (mpc_jit.h, -DMPC_JIT_ANYROOT); gen_layout is 1 */
+  int32_t gather_unrolled; /* 1: some DIFF / WEIGHT module has a BaseIndexTable that is not windowed: only a kernel compiled at
+                           creation with the tables as constants (mpc_jit.h, -DMPC_JIT_GATHER) evaluates it on the fast path;
+                           without one the handle falls back to the generic kernel */
   int32_t planes_differ; /* 1: plane-major tables that stop after a whole number of bit planes, NOT the same number in every
                            module (MpcFastModule::plane_mask): only a kernel compiled at creation evaluates it (mpc_jit.h,
                            -DMPC_JIT_PLANES); without one the handle falls back to the generic kernel */

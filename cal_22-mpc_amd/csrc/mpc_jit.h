@@ -83,6 +83,13 @@ inline std::string kinds_of(const MpcVpcParams &P)
   return s;
 }
 
+inline std::string gathers_of(const MpcVpcParams &P)
+{
+  std::string s;
+  for (int q = 0; q < P.n_pred; q++) s += (q ? ", " : "") + std::to_string(P.fm[q].gather ? 1 : 0);
+  return s;
+}
+
 inline std::string roots_of(const MpcVpcParams &P)
 {
   std::string s;
@@ -95,7 +102,7 @@ inline bool eligible(const MpcVpcParams &P, bool fast)
 {
   const char *env = std::getenv("MPC_JIT");
   if (env && std::strcmp(env, "0") == 0) return false;
-  if (!fast || (P.runtime_only && !P.bm_unrolled && !P.anyroot_unrolled && !P.planes_differ) || P.n_pred < 1 || P.n_pred > max_modules()) return false;
+  if (!fast || (P.runtime_only && !P.bm_unrolled && !P.anyroot_unrolled && !P.planes_differ && !P.gather_unrolled) || P.n_pred < 1 || P.n_pred > max_modules()) return false;
   if (!(P.L == 32 || P.L == 64 || P.L == 128)) return false;
   if (mpc_vpc_lane_unrolled(&P)) return false;            // built in (never the byte-major order)
   unsigned ring_cfg = 0;
@@ -186,7 +193,22 @@ inline Rtc &rtc()
 }  // namespace detail
 
 // the translation unit handed to hiprtc: the lane kernel's device code and two kernels of the sequence
-inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testing)
+// gtab: the HOST copy of the generic-path tables (VpcPlan::gtab: every module's BaseIndexTable at gm[q].off_base)
+inline std::string bases_of(const MpcVpcParams &P, const unsigned char *gtab)
+{
+  std::string s;
+  for (int q = 0; q < P.n_pred; q++) {
+    s += q ? ", {" : "{";
+    for (int i = 0; i < P.L; i++) {
+      const bool has = P.fm[q].gather && gtab && i != P.fm[q].root;
+      s += (i ? "," : "") + std::to_string(has ? (int)gtab[P.gm[q].off_base + i] : -1);
+    }
+    s += "}";
+  }
+  return s;
+}
+
+inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testing, const unsigned char *gtab = nullptr)
 {
   const int W = P.L / 4;
   int wpb = 0;
@@ -197,6 +219,9 @@ inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testi
     << "#define MPC_JIT_BM " << (P.bm_unrolled ? 1 : 0) << "\n"
     << "#define MPC_JIT_ANYROOT " << (P.anyroot_unrolled ? 1 : 0) << "\n"
     << "#define MPC_JIT_PLANES " << (P.planes_differ ? 1 : 0) << "\n"
+    << "#define MPC_JIT_GATHER " << (P.gather_unrolled ? 1 : 0) << "\n"
+    << "#define MPC_JIT_GATHERS " << gathers_of(P) << "\n"
+    << "#define MPC_JIT_BASES " << (P.gather_unrolled ? bases_of(P, gtab) : std::string("{0}")) << "\n"
     << "#define MPC_JIT_ROOTS " << roots_of(P) << "\n"
     << "#define MPC_TESTING " << testing << "\n"
     << "#define " << (P.L <= 32 ? "MPC_LANE_WAVES_32 " : P.L <= 64 ? "MPC_LANE_WAVES " : "MPC_LANE_WAVES_128 ") << wpb << "      /* waves per workgroup of the LDS plan */\n"
@@ -325,7 +350,7 @@ inline bool compile(const std::string &source, const std::string &arch, const st
 
 // Compile (or take from the cache) and load the two kernels of P's sequence on the current device.
 // Returns false with a reason in `why`; the caller then runs the run-time module loop.
-inline bool build(const MpcVpcParams &P, int testing, Kernels &out, std::string &why)
+inline bool build(const MpcVpcParams &P, int testing, Kernels &out, std::string &why, const unsigned char *gtab = nullptr)
 {
   unsigned ring_cfg = 0;
   const size_t smem = mpc_vpc_lane_ring_plan(&P, &ring_cfg, nullptr);
@@ -342,7 +367,7 @@ inline bool build(const MpcVpcParams &P, int testing, Kernels &out, std::string 
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { why = "no device"; return false; }
   const std::string arch = prop.gcnArchName;
   if (arch.compare(0, 6, "gfx950") != 0) { why = "device is " + arch + ", the kernels are written for gfx950"; return false; }
-  const std::string source = source_of(P, smem, testing);
+  const std::string source = source_of(P, smem, testing, gtab);
 
   // ---- cache: keyed by everything the code object depends on ----
   // (the compiler's version enters through the HIP runtime's: they are installed together)

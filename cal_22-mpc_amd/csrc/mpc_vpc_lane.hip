@@ -51,6 +51,13 @@
 #ifndef MPC_JIT_PLANES
 #define MPC_JIT_PLANES 0
 #endif
+// 1 only in a translation unit that mpc_jit.h compiles for a configuration in which a DiffBase / WeightBase module's
+// BaseIndexTable is not windowed: MPC_JIT_BASES then holds every module's table (-1: predicted byte forced to 0),
+// MPC_JIT_GATHERS which modules gather, and the base bytes of a word come from wherever the table says -- constants, so each
+// word costs at most three v_perm_b32.
+#ifndef MPC_JIT_GATHER
+#define MPC_JIT_GATHER 0
+#endif
 #ifndef MPC_ABLATE
 #define MPC_ABLATE 0   // development-only timing ablations (tools/ablate.sh); results are WRONG when non-zero
 #endif
@@ -71,13 +78,19 @@ __device__ __host__ constexpr int lk_dist(int kind) { return (kind & LK_PW2) ? 2
 typedef const u32 __attribute__((address_space(4))) *ctab_t;
 __device__ __forceinline__ ctab_t lane_tab(const MpcVpcParams &P) { return (ctab_t)(u64)P.tab; }
 
-#if MPC_JIT_ANYROOT
+#if MPC_JIT_ANYROOT || MPC_JIT_GATHER
 template <int Q>
 __device__ __forceinline__ MpcFastModule lane_fm_const(const MpcVpcParams &P)
 {
-  constexpr int roots[] = {MPC_JIT_ROOTS};
   MpcFastModule f = P.fm[Q];
+#if MPC_JIT_ANYROOT
+  constexpr int roots[] = {MPC_JIT_ROOTS};
   f.root = roots[Q];
+#endif
+#if MPC_JIT_GATHER
+  constexpr int gathers[] = {MPC_JIT_GATHERS};
+  f.gather = gathers[Q] ? Q + 1 : 0;      // (a constant: which table lane_gather_base reads)
+#endif
   return f;
 }
 #define LANE_FM(Q) lane_fm_const<Q>(P)
@@ -175,6 +188,24 @@ __device__ __forceinline__ u32 window_predict(u32 b, u32 c1, u32 c2, const MpcFa
     return (((b << fm.ls1) >> fm.rs1) & c1) | (((b << fm.ls2) >> fm.rs2) & c2);
 }
 
+#if MPC_JIT_GATHER
+// base bytes of word e of module q from anywhere in the line (q, e and the table are constants once this is inlined)
+template <int W>
+__device__ __forceinline__ u32 lane_gather_base(const Lane<W> &c, int q, int e)
+{
+  constexpr short bases[][4 * W] = {MPC_JIT_BASES};
+  u32 half[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int b0 = bases[q][4 * e + 2 * h], b1 = bases[q][4 * e + 2 * h + 1];
+    const u32 w0 = b0 >= 0 ? c.x[b0 >> 2] : 0u, w1 = b1 >= 0 ? c.x[b1 >> 2] : 0u;
+    const u32 sel = (b0 >= 0 ? (u32)(b0 & 3) : 0x0cu) | ((b1 >= 0 ? 4u + (u32)(b1 & 3) : 0x0cu) << 8) | 0x0c0c0000u;
+    half[h] = perm(w1, w0, sel);            // [byte b0, byte b1, 0, 0]
+  }
+  return perm(half[1], half[0], 0x05040100u);
+}
+#endif
+
 // base bytes of word e: own / previous word through v_perm_b32, or simply the previous word
 template <int W, int KIND>
 __device__ __forceinline__ u32 window_base(const Lane<W> &c, int e, ctab_t t)
@@ -189,7 +220,11 @@ __device__ __forceinline__ u32 window_base(const Lane<W> &c, int e, ctab_t t)
 template <int W, int KIND, bool FULL = true>
 __device__ __forceinline__ u32 window_residue(const Lane<W> &c, int e, ctab_t t, const MpcFastModule &fm)
 {
+#if MPC_JIT_GATHER
+  const u32 b = fm.gather ? lane_gather_base<W>(c, fm.gather - 1, e) : window_base<W, KIND>(c, e, t);
+#else
   const u32 b = window_base<W, KIND>(c, e, t);
+#endif
   constexpr int D = lk_dist(KIND);
   const int k = D == 2 ? (e < 2 ? e : 2 + (e & 1)) : (D == 1 ? (e ? 1 : 0) : e);     // table entry of word e
   if constexpr (lk_base(KIND) == MPC_FK_WEIGHT) {

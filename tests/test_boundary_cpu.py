@@ -80,9 +80,21 @@ def test_custom_encoding_bits_and_generic_classification(mpc, configs):
     scan["Rows"][0], scan["Rows"][100] = scan["Rows"][100], scan["Rows"][0]
     cfg = configs.make_config(64, [{"name": "AllZero"}, configs.one_base(64, scan=scan)])
     assert mpc.describe_config(cfg)["path"] == "generic"
-    # base table outside the own/previous dword -> generic kernel
+    # base table outside the own/previous dword -> compiled at creation with the table as constants (a byte gather); the generic
+    # kernel only when that is switched off, or when the table comes with another layout the built-in kernels lack
     base = [0] * 64
     cfg = configs.make_config(64, [{"name": "AllZero"}, configs.diff_base(64, base, [0] * 64)])
+    d = mpc.describe_config(cfg)
+    assert d["path"] == "fast" and d["sequence"] == "unrolled" and d["compiled"] == "at creation", d
+    assert mpc.jit_compile_check(cfg) > 10000
+    os.environ["MPC_JIT"] = "0"
+    try:
+        d = mpc.describe_config(cfg)
+        assert d["path"] == "generic" and "not windowed" in d["why_generic"], d
+    finally:
+        del os.environ["MPC_JIT"]
+    bm = {"TableSize": 512, "Rows": [i % 8 for i in range(512)], "Cols": [i // 8 for i in range(512)]}
+    cfg = configs.make_config(64, [{"name": "AllZero"}, configs.diff_base(64, base, [0] * 64, 0, True, bm)])
     assert mpc.describe_config(cfg)["path"] == "generic"
 
 

@@ -102,9 +102,16 @@ def test_vpc_lane_kernel_sequences(mpc, oracle, configs, traces, L):
                  [az, aws, configs.weight_base(L, two_back, [[2.0, 0.5][i % 2] for i in range(L)], 0, True),
                   configs.diff_base(L, prev_word, diff, 0, False)]):
         _check_vpc(mpc, oracle, configs.make_config(L, mods), lines64, expect_path=mpc.MPC_PATH_VPC_FAST)
-    # i - 8 bases whose constants do not repeat every 8 bytes have no fast form: generic kernel
+    # i - 8 bases whose constants do not repeat every 8 bytes have no built-in form: compiled at creation with a byte gather
+    # (the table as constants), the generic kernel without the run-time compiler
     odd = configs.make_config(L, [az, configs.diff_base(L, two_back, diff, 0, True)])
-    _check_vpc(mpc, oracle, odd, lines64[:3000], expect_path=mpc.MPC_PATH_VPC_GENERIC)
+    assert mpc.describe_config(odd)["compiled"] == "at creation"
+    _check_vpc(mpc, oracle, odd, lines64[:3000], expect_path=mpc.MPC_PATH_VPC_FAST)
+    os.environ["MPC_JIT"] = "0"
+    try:
+        _check_vpc(mpc, oracle, odd, lines64[:3000], expect_path=mpc.MPC_PATH_VPC_GENERIC)
+    finally:
+        del os.environ["MPC_JIT"]
 
 
 def test_vpc_matches_reference_line_vectors(mpc, oracle):
@@ -422,6 +429,20 @@ def test_vpc_sequences_compiled_at_creation(mpc, oracle, configs, traces, L, tmp
     run(configs.make_config(L, [az, aws, configs.consecutive_base(L, 0, True, sb)]), "unrolled, compiled at creation")
     run(configs.make_config(L, [az, aws, configs.one_base(L, 6, True, sb), configs.consecutive_base(L, 0, False, sb)]), "run-time loop")
     run(configs.make_config(L, [az, aws, configs.one_base(L, 0, True, bytemajor(8)), configs.consecutive_base(L, 0, False, bytemajor(8))]), "run-time loop")
+    # base tables that are not windowed (a base byte anywhere in the line: 16 / 12 bytes back, byte 0 for all, reversed):
+    # gathered with the table as compile-time constants -- round 2 ran these on the generic kernel
+    prev16 = [max(i - 16, 0) for i in range(L)]
+    prev12 = [max(i - 12, 0) for i in range(L)]
+    rev = [L - 1 - i for i in range(L)]
+    for mods in ([az, aws, configs.one_base(L, 0, True), configs.consecutive_base(L, 0, True), configs.diff_base(L, prev16, diff, 0, False),
+                  configs.weight_base(L, prev12, w2, 0, True)],
+                 [az, configs.diff_base(L, [0] * L, [1] * L, 0, True), configs.weight_base(L, prev4, w2, 3, False)],
+                 [az, aws, configs.weight_base(L, rev, w3, 5, True, trunc(6 * L)), configs.one_base(L, 3, False, trunc(6 * L)),
+                  configs.diff_base(L, prev16, diff, 9, True, trunc(6 * L))]):
+        cfg = configs.make_config(L, mods)
+        d = mpc.describe_config(cfg)
+        assert d["path"] == "fast" and d["compiled"] == "at creation", d
+        run(cfg, "unrolled, compiled at creation")
     if L == 64:      # the longest sequence that is compiled (12 prediction modules; the kernel spills registers but beats the loop)
         twelve = seqs["8 modules"](None, (0, 0, 0)) + [configs.one_base(L, 0, False), configs.diff_base(L, prev1, diff, 0, True),
                                                         configs.weight_base(L, prev4, w2, 0, False), configs.consecutive_base(L, 0, True)]
@@ -558,7 +579,15 @@ def test_generic_and_fast_agree(mpc, configs, traces):
     eq = configs.make_config(L, [{"name": "AllZero"}, {"name": "AllWordSame"},
                                  configs.diff_base(L, [0] * L, [0] * L, 0, True),
                                  cfg["modules"]["3"], cfg["modules"]["4"], cfg["modules"]["5"]])
-    gen = mpc.VPC(eq)
+    jit = mpc.VPC(eq)                         # ... compiled at creation with the base table as constants (a byte gather)
+    assert jit.kernel_path == mpc.MPC_PATH_VPC_FAST and jit.kernel_form.startswith("unrolled, compiled at creation"), jit.kernel_form
+    s3, c3 = jit.compress_lines(lines)
+    assert (s1 == s3).all() and (c1 == c3).all()
+    os.environ["MPC_JIT"] = "0"                 # ... and without the run-time compiler on the generic kernel
+    try:
+        gen = mpc.VPC(eq)
+    finally:
+        del os.environ["MPC_JIT"]
     assert gen.kernel_path == mpc.MPC_PATH_VPC_GENERIC and "windowed" in gen.path_reason and fast.path_reason == ""
     s2, c2 = gen.compress_lines(lines)
     assert (s1 == s2).all() and (c1 == c2).all()
