@@ -188,15 +188,16 @@ int create_vpc_from_text(const std::string &text, int device, mpc_handle **out)
       (void)hipSetDevice(h->device);
       if (!mpcjit::build(h->plan.params, MPC_TESTING, h->jit, why, h->plan.gtab.data()))
         std::fprintf(stderr, "libmpc_hip: module sequence [%s] runs the %s: %s\n", mpcjit::kinds_of(h->plan.params).c_str(),
-                     (h->plan.params.planes_differ || h->plan.params.gather_unrolled) ? "generic kernel (some hundred times slower)" : "run-time module loop (several times slower)",
+                     (h->plan.params.planes_differ || h->plan.params.gather_unrolled || h->plan.params.wshift_unrolled) ? "generic kernel (some hundred times slower)" : "run-time module loop (several times slower)",
                      why.c_str());
     }
-    if (h->plan.fast && (h->plan.params.planes_differ || h->plan.params.gather_unrolled) && !h->jit.mod) {
+    if (h->plan.fast && (h->plan.params.planes_differ || h->plan.params.gather_unrolled || h->plan.params.wshift_unrolled) && !h->jit.mod) {
       // scan tables of different sizes, base tables that are not windowed: only a kernel compiled at creation evaluates them
       // on the fast path
       h->plan.fast = false;
       h->plan.why_generic = h->plan.params.planes_differ ? "scan tables of different sizes, and the kernel for them could not be compiled at creation"
-                                                         : "BaseIndexTable is not windowed (own/previous dword), and the kernel for it could not be compiled at creation";
+                                                         : h->plan.params.gather_unrolled ? "BaseIndexTable is not windowed (own/previous dword), and the kernel for it could not be compiled at creation"
+                                                         : "WeightTable uses more than two shift distances, and the kernel for it could not be compiled at creation";
     }
     // the statistics accumulators of a workgroup live in LDS
     const size_t smem = h->jit.mod ? mpc_vpc_lane_ring_plan(&h->plan.params, nullptr, nullptr)
@@ -1024,10 +1025,11 @@ int mpc_config_describe(const char *json_text, char *out, size_t cap)
   } else {
     mpc::VpcPlan plan;
     mpc::build_vpc_plan(cfg, plan);
-    if (plan.fast && (plan.params.planes_differ || plan.params.gather_unrolled) && !mpcjit::eligible(plan.params, true)) {      // (as mpc_create_vpc* decides)
+    if (plan.fast && (plan.params.planes_differ || plan.params.gather_unrolled || plan.params.wshift_unrolled) && !mpcjit::eligible(plan.params, true)) {      // (as mpc_create_vpc* decides)
       plan.fast = false;
       plan.why_generic = plan.params.planes_differ ? "scan tables of different sizes, and run-time compilation is not available for them"
-                                                   : "BaseIndexTable is not windowed (own/previous dword), and run-time compilation is not available for it";
+                                                   : plan.params.gather_unrolled ? "BaseIndexTable is not windowed (own/previous dword), and run-time compilation is not available for it"
+                                                   : "WeightTable uses more than two shift distances, and run-time compilation is not available for it";
     }
     s = "{\"L\": " + std::to_string(cfg.L) + ", \"M\": " + std::to_string(cfg.M) + ", \"n_pred\": " + std::to_string(cfg.n_pred) +
         ", \"has_aws\": " + (cfg.has_aws ? "true" : "false") + ", \"hist_bins\": " + std::to_string(cfg.hist_bins) + ", \"enc_bits\": [";

@@ -312,6 +312,7 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     int shifts[2] = {0, 0}, nshift = 0;
     bool stride2 = L >= 16 && m.root < 8;       // (words 0 and 1 have table entries of their own)
     for (int i = 8; i < L; i++) stride2 = stride2 && m.base[(size_t)i] == i - 8;
+    bool wgen = false;                           // more than two shift distances: assembled from the table as constants (mpc_jit.h)
     bool gather = false;                         // a base byte outside the window: gathered with the table as constants (mpc_jit.h)
     for (int i = 0; i < L && plan.fast; i++) {
       const int w = i / 4, k = i % 4;
@@ -337,7 +338,7 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
         int cls = -1;
         for (int c = 0; c < nshift; c++) if (shifts[c] == sh) cls = c;
         if (cls < 0) {
-          if (nshift == 2) { no(tag + "WeightTable uses more than two shift distances"); break; }
+          if (nshift == 2) { wgen = true; continue; }
           cls = nshift;
           shifts[nshift++] = sh;
         }
@@ -360,7 +361,11 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
         std::swap(c1, c2);
       }
       // MPC_FK_WEIGHT: class 1 unshifted, class 2 a right shift (or absent); anything else is WEIGHT2
-      f.kind = (shifts[0] == 0 && shifts[1] <= 0) ? MPC_FK_WEIGHT : MPC_FK_WEIGHT2;
+      f.kind = (!wgen && shifts[0] == 0 && shifts[1] <= 0) ? MPC_FK_WEIGHT : MPC_FK_WEIGHT2;
+      if (wgen) {
+        f.wgen = 1;
+        P.wshift_unrolled = 1;
+      }
       f.ls1 = shifts[0] > 0 ? shifts[0] : 0;
       f.rs1 = shifts[0] < 0 ? -shifts[0] : 0;
       f.ls2 = shifts[1] > 0 ? shifts[1] : 0;
@@ -375,13 +380,13 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     if (gather) {
       f.gather = 1;
       P.gather_unrolled = 1;
-      stride2 = false;
     }
+    if (gather || wgen) stride2 = false;
     // periodic tables: words 1.. all use "the same byte of the previous word" with identical masks /
     // constants, so the kernel needs neither the byte gather nor per-word table entries
     f.prev_word = 1;
     for (size_t w = 1; w < sel.size(); w++)
-      if (gather || sel[w] != 0x03020100u || c1[w] != c1[1] || c2[w] != c2[1]) f.prev_word = 0;
+      if (gather || wgen || sel[w] != 0x03020100u || c1[w] != c1[1] || c2[w] != c2[1]) f.prev_word = 0;
     if (stride2) {
       // two-words-back tables must repeat with the element (2 words) from word 2 on: the kernel
       // has no byte gather for them and reads the entries of words 2 and 3 for even / odd words
@@ -397,10 +402,11 @@ inline void build_vpc_plan(const VpcConfig &cfg, VpcPlan &plan)
     }
   }
   if (P.runtime_only) P.gen_layout = 0;
-  if (plan.fast && P.gather_unrolled) {
+  if (plan.fast && (P.gather_unrolled || P.wshift_unrolled)) {
     if (P.byte_major || P.runtime_only || P.planes_differ) {
       plan.fast = false;
-      plan.why_generic = "BaseIndexTable is not windowed (own/previous dword), together with another layout the built-in kernels lack";
+      plan.why_generic = P.gather_unrolled ? "BaseIndexTable is not windowed (own/previous dword), together with another layout the built-in kernels lack"
+                                           : "WeightTable uses more than two shift distances, together with another layout the built-in kernels lack";
     } else {
       P.runtime_only = 1;        // no built-in kernel, and not the run-time loop either (its byte gather is the windowed one)
     }

@@ -41,6 +41,8 @@ struct MpcFastModule {
                          ONEBASE / DIFF / WEIGHT* on the run-time loop) */
   int32_t gather;     /* DIFF / WEIGHT*: 1 = the BaseIndexTable is not windowed (a base byte outside the own / previous dword): the
                          base bytes are gathered with the table as compile-time constants (gather_unrolled configurations) */
+  int32_t wgen;       /* WEIGHT*: 1 = the WeightTable has more than two shift distances: the predicted word is assembled from the
+                         table as compile-time constants (wshift_unrolled configurations) */
   uint32_t plane_mask; /* this module's scanned bit planes, in every byte (planes_differ configurations; else unused) */
   int32_t prev_word;  /* DIFF/WEIGHT periodic tables.  1: every base byte of words 1.. is the same byte of the
                          previous word (BaseIndexTable[i] = i - 4) and the table entries of words 1.. are
@@ -93,6 +95,7 @@ struct MpcVpcParams {
   int32_t anyroot_unrolled; /* 1: plane-major order, complete first row, some RootIndex above 15: no built-in kernel (runtime_only
                            stays 1), but the general-layout kernels can be compiled for it at handle creation with the roots as
                            constants (mpc_jit.h, -DMPC_JIT_ANYROOT); gen_layout is 1 */
+  int32_t wshift_unrolled; /* 1: some WEIGHT module has more than two shift distances (like gather_unrolled: -DMPC_JIT_WSHIFT) */
   int32_t gather_unrolled; /* 1: some DIFF / WEIGHT module has a BaseIndexTable that is not windowed: only a kernel compiled at
                            creation with the tables as constants (mpc_jit.h, -DMPC_JIT_GATHER) evaluates it on the fast path;
                            without one the handle falls back to the generic kernel */

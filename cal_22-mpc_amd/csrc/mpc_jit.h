@@ -37,6 +37,8 @@
 #include <cstring>
 #include <fcntl.h>
 #include <fstream>
+#include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -65,11 +67,18 @@ struct Kernels {
   bool from_cache = false;
 };
 
-inline void unload(Kernels &k)
-{
-  if (k.mod) (void)hipModuleUnload(k.mod);
-  k = Kernels();
-}
+// Loaded modules belong to the process, not to a handle: they are kept (with the code object image they were loaded from)
+// until the process ends and shared by every handle of the same configuration shape on the same device.  A handle's
+// Kernels are borrowed references; nothing is ever unloaded (a module is ~100 KB of device memory).
+struct Loaded {
+  hipModule_t mod = nullptr;
+  hipFunction_t stats = nullptr, lines = nullptr;
+  std::string image;      // the code object, alive as long as the module
+};
+inline std::mutex &loaded_mutex() { static std::mutex m; return m; }
+inline std::map<std::string, Loaded *> &loaded_modules() { static std::map<std::string, Loaded *> m; return m; }
+
+inline void unload(Kernels &k) { k = Kernels(); }
 
 // the sequence as the kernels' template arguments (lane-kernel kinds: MPC_FK_* | 8 / 16 for periodic tables)
 inline std::string kinds_of(const MpcVpcParams &P)
@@ -80,6 +89,13 @@ inline std::string kinds_of(const MpcVpcParams &P)
     const int kind = f.kind | (f.prev_word == 1 ? 8 : (f.prev_word == 2 ? 16 : 0));
     s += (q ? ", " : "") + std::to_string(kind);
   }
+  return s;
+}
+
+inline std::string wgens_of(const MpcVpcParams &P)
+{
+  std::string s;
+  for (int q = 0; q < P.n_pred; q++) s += (q ? ", " : "") + std::to_string(P.fm[q].wgen ? 1 : 0);
   return s;
 }
 
@@ -102,7 +118,7 @@ inline bool eligible(const MpcVpcParams &P, bool fast)
 {
   const char *env = std::getenv("MPC_JIT");
   if (env && std::strcmp(env, "0") == 0) return false;
-  if (!fast || (P.runtime_only && !P.bm_unrolled && !P.anyroot_unrolled && !P.planes_differ && !P.gather_unrolled) || P.n_pred < 1 || P.n_pred > max_modules()) return false;
+  if (!fast || (P.runtime_only && !P.bm_unrolled && !P.anyroot_unrolled && !P.planes_differ && !P.gather_unrolled && !P.wshift_unrolled) || P.n_pred < 1 || P.n_pred > max_modules()) return false;
   if (!(P.L == 32 || P.L == 64 || P.L == 128)) return false;
   if (mpc_vpc_lane_unrolled(&P)) return false;            // built in (never the byte-major order)
   unsigned ring_cfg = 0;
@@ -208,6 +224,25 @@ inline std::string bases_of(const MpcVpcParams &P, const unsigned char *gtab)
   return s;
 }
 
+// every module's shift distance per byte (VpcPlan::gtab at gm[q].off_shift, clamped to +-8); 99: the predicted byte is 0
+inline std::string shifts_of(const MpcVpcParams &P, const unsigned char *gtab)
+{
+  std::string s;
+  for (int q = 0; q < P.n_pred; q++) {
+    s += q ? ", {" : "{";
+    for (int i = 0; i < P.L; i++) {
+      int v = 99;
+      if (P.fm[q].wgen && gtab && i != P.fm[q].root) {
+        v = (int)(signed char)gtab[P.gm[q].off_shift + i];
+        if (v >= 8 || v <= -8) v = 99;
+      }
+      s += (i ? "," : "") + std::to_string(v);
+    }
+    s += "}";
+  }
+  return s;
+}
+
 inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testing, const unsigned char *gtab = nullptr)
 {
   const int W = P.L / 4;
@@ -219,6 +254,9 @@ inline std::string source_of(const MpcVpcParams &P, size_t smem_bytes, int testi
     << "#define MPC_JIT_BM " << (P.bm_unrolled ? 1 : 0) << "\n"
     << "#define MPC_JIT_ANYROOT " << (P.anyroot_unrolled ? 1 : 0) << "\n"
     << "#define MPC_JIT_PLANES " << (P.planes_differ ? 1 : 0) << "\n"
+    << "#define MPC_JIT_WSHIFT " << (P.wshift_unrolled ? 1 : 0) << "\n"
+    << "#define MPC_JIT_WGENS " << wgens_of(P) << "\n"
+    << "#define MPC_JIT_SHIFTS " << (P.wshift_unrolled ? shifts_of(P, gtab) : std::string("{0}")) << "\n"
     << "#define MPC_JIT_GATHER " << (P.gather_unrolled ? 1 : 0) << "\n"
     << "#define MPC_JIT_GATHERS " << gathers_of(P) << "\n"
     << "#define MPC_JIT_BASES " << (P.gather_unrolled ? bases_of(P, gtab) : std::string("{0}")) << "\n"
@@ -377,11 +415,33 @@ inline bool build(const MpcVpcParams &P, int testing, Kernels &out, std::string 
   std::snprintf(key, sizeof key, "%016llx", detail::fnv1a(source + all_sources + "|" + arch + "|" + std::to_string(rtv)));
   const std::string cdir = detail::cache_dir();
   const std::string cpath = cdir.empty() ? "" : cdir + "/lane_" + key + ".hsaco";
+  const std::string mem_key = std::string(key) + "@" + std::to_string(dev);
+  std::lock_guard<std::mutex> lock(loaded_mutex());
+  {
+    auto it = loaded_modules().find(mem_key);
+    if (it != loaded_modules().end()) {        // this process has it loaded on this device already
+      out.mod = it->second->mod;
+      out.stats = it->second->stats;
+      out.lines = it->second->lines;
+      out.from_cache = true;
+      return true;
+    }
+  }
   auto load = [&](const std::string &code) -> hipError_t {
-    hipError_t e = hipModuleLoadData(&out.mod, code.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&out.stats, out.mod, "mpc_jit_stats");
-    if (e == hipSuccess) e = hipModuleGetFunction(&out.lines, out.mod, "mpc_jit_lines");
-    if (e != hipSuccess) unload(out);
+    Loaded *L = new Loaded;
+    L->image = code;                            // the runtime may keep pointing into the image: it lives as long as the module
+    hipError_t e = hipModuleLoadData(&L->mod, L->image.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&L->stats, L->mod, "mpc_jit_stats");
+    if (e == hipSuccess) e = hipModuleGetFunction(&L->lines, L->mod, "mpc_jit_lines");
+    if (e != hipSuccess) {
+      if (L->mod) (void)hipModuleUnload(L->mod);
+      delete L;
+      return e;
+    }
+    loaded_modules()[mem_key] = L;
+    out.mod = L->mod;
+    out.stats = L->stats;
+    out.lines = L->lines;
     return e;
   };
   std::string code;

@@ -58,6 +58,12 @@
 #ifndef MPC_JIT_GATHER
 #define MPC_JIT_GATHER 0
 #endif
+// 1 only in a translation unit that mpc_jit.h compiles for a configuration in which a WeightBase module's WeightTable has more
+// than two shift distances: MPC_JIT_SHIFTS holds every module's shift per byte (99: the predicted byte is 0), MPC_JIT_WGENS
+// which modules take them from there.
+#ifndef MPC_JIT_WSHIFT
+#define MPC_JIT_WSHIFT 0
+#endif
 #ifndef MPC_ABLATE
 #define MPC_ABLATE 0   // development-only timing ablations (tools/ablate.sh); results are WRONG when non-zero
 #endif
@@ -78,7 +84,7 @@ __device__ __host__ constexpr int lk_dist(int kind) { return (kind & LK_PW2) ? 2
 typedef const u32 __attribute__((address_space(4))) *ctab_t;
 __device__ __forceinline__ ctab_t lane_tab(const MpcVpcParams &P) { return (ctab_t)(u64)P.tab; }
 
-#if MPC_JIT_ANYROOT || MPC_JIT_GATHER
+#if MPC_JIT_ANYROOT || MPC_JIT_GATHER || MPC_JIT_WSHIFT
 template <int Q>
 __device__ __forceinline__ MpcFastModule lane_fm_const(const MpcVpcParams &P)
 {
@@ -90,6 +96,10 @@ __device__ __forceinline__ MpcFastModule lane_fm_const(const MpcVpcParams &P)
 #if MPC_JIT_GATHER
   constexpr int gathers[] = {MPC_JIT_GATHERS};
   f.gather = gathers[Q] ? Q + 1 : 0;      // (a constant: which table lane_gather_base reads)
+#endif
+#if MPC_JIT_WSHIFT
+  constexpr int wgens[] = {MPC_JIT_WGENS};
+  f.wgen = wgens[Q] ? Q + 1 : 0;
 #endif
   return f;
 }
@@ -206,6 +216,25 @@ __device__ __forceinline__ u32 lane_gather_base(const Lane<W> &c, int q, int e)
 }
 #endif
 
+#if MPC_JIT_WSHIFT
+// WeightBase with any number of shift distances: the predicted word from the base bytes b, byte by byte (PredictorModule.cpp:57-62:
+// base >> |s| or base << s in uint8); q, e and the table are constants once this is inlined, equal shifts fold into one
+template <int W>
+__device__ __forceinline__ u32 lane_weight_general(u32 b, int q, int e)
+{
+  constexpr signed char sh[][4 * W] = {MPC_JIT_SHIFTS};
+  u32 pred = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int s = sh[q][4 * e + k];
+    if (s == 99) continue;
+    const u32 keep = (s >= 0 ? ((0xffu << s) & 0xffu) : (0xffu >> -s)) << (8 * k);      // the bits that stay inside the byte
+    pred |= (s >= 0 ? (b << s) : (b >> -s)) & keep;
+  }
+  return pred;
+}
+#endif
+
 // base bytes of word e: own / previous word through v_perm_b32, or simply the previous word
 template <int W, int KIND>
 __device__ __forceinline__ u32 window_base(const Lane<W> &c, int e, ctab_t t)
@@ -235,7 +264,11 @@ __device__ __forceinline__ u32 window_residue(const Lane<W> &c, int e, ctab_t t,
     const u32 w = c.x[e] ^ (b & t[4 * W + k]);          // bit 7: line ^ predicted
     return FULL ? (sub ^ (~w & H80)) : (sub ^ ~w);
   } else {
+#if MPC_JIT_WSHIFT
+    const u32 pred = fm.wgen ? lane_weight_general<W>(b, fm.wgen - 1, e) : window_predict<lk_base(KIND)>(b, t[W + k], t[2 * W + k], fm);
+#else
     const u32 pred = window_predict<lk_base(KIND)>(b, t[W + k], t[2 * W + k], fm);
+#endif
     return FULL ? bsub(c.x[e], pred) : msb_of_bsub(c.x[e], pred);
   }
 }
