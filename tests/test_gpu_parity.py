@@ -332,7 +332,8 @@ def test_vpc_general_layout_twins(mpc, oracle, configs, traces, L):
         check(probe(roots, ts), True, 5000)
     # a root above 15: no built-in twin takes it; the general-layout kernel is compiled at creation with the roots as constants
     # (the rotation then reaches beyond row 0, and the prefilter drops natural byte 15 for the raw root)
-    for roots, ts in (((16, 0, 0), None), ((L - 1, 17, L // 2 + 1), None), ((5, 20, 0), 6 * L), ((19, L - 2, 16), 4 * L + 7)):
+    far = (((16, 0, 0), None), ((L - 1, 17, L // 2 + 1), None), ((5, 20, 0), 6 * L), ((19, L - 2, 16), 4 * L + 7))
+    for roots, ts in (far if L == 64 else far[1:3]):           # (each case is a compilation: all of them at 64-byte lines only)
         cfg = probe(roots, ts)
         assert mpc.describe_config(cfg)["compiled"] == "at creation"
         check(cfg, True, 5000)
@@ -341,7 +342,8 @@ def test_vpc_general_layout_twins(mpc, oracle, configs, traces, L):
         ev.close()
     # every module its own number of bit planes (no built-in kernel, not the run-time loop either: compiled at creation with a
     # mask per module; the winner's mask goes with it to the XOR stage) -- round 2 ran these on the generic kernel
-    for sizes, roots in (((8, 6, 4, 7), (0, 3, 0)), ((3, 8, 8, 1), (5, 0, 2)), ((8, 8, 8, 2), (0, 0, 0))):
+    planes = (((8, 6, 4, 7), (0, 3, 0)), ((3, 8, 8, 1), (5, 0, 2)), ((8, 8, 8, 2), (0, 0, 0)))
+    for sizes, roots in (planes if L == 64 else planes[:2]):
         mods = [az, aws, configs.one_base(L, roots[0], True, trunc(sizes[0] * L)), configs.consecutive_base(L, 0, True, trunc(sizes[1] * L)),
                 configs.diff_base(L, prev4, d1, roots[1], False, trunc(sizes[2] * L)), configs.weight_base(L, prev4, w2, roots[2], True, trunc(sizes[3] * L))]
         cfg = configs.make_config(L, mods)
@@ -408,14 +410,15 @@ def test_vpc_sequences_compiled_at_creation(mpc, oracle, configs, traces, L, tmp
             d = mpc.describe_config(cfg)
             assert d["sequence"] == "unrolled" and d["compiled"] == "at creation" and d["general_layout"] == ("yes" if ts else "no"), (name, d)
             run(cfg, "unrolled, compiled at creation")       # (compiled now, unless an earlier test of this process had the same shape)
-            assert run(cfg, "unrolled, compiled at creation") == "unrolled, compiled at creation (from the cache)"
+            if L == 64 or name == "OB DF WT OB":
+                assert run(cfg, "unrolled, compiled at creation") == "unrolled, compiled at creation (from the cache)"
     # the byte-major scan order (rows = byte pairs): no built-in kernel has it; with every RootIndex 0 the unrolled kernels are
     # compiled for it (its own selector, row-0 prefilter, certificate and encoder), full and truncated tables; a root elsewhere
     # keeps the run-time loop
     def bytemajor(ts=8 * L):
         return {"TableSize": ts, "Rows": [i % 8 for i in range(ts)], "Cols": [i // 8 for i in range(ts)]}
     d1 = [1 if i % 4 == 0 else 0 for i in range(L)]
-    for ts in (8 * L, 8 * L - 20, 5 * L + 3, 24, 16):
+    for ts in ((8 * L, 8 * L - 20, 5 * L + 3, 24, 16) if L == 64 else (8 * L, 5 * L + 3)):      # (each case is a compilation)
         sb = bytemajor(ts)
         cfg = configs.make_config(L, [az, aws, configs.one_base(L, 0, True, sb), configs.consecutive_base(L, 0, True, sb),
                                       configs.diff_base(L, prev4, d1, 0, False, sb), configs.weight_base(L, prev4, w2, 0, True, sb)])
