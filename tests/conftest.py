@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 PKG = "cal_22-mpc_amd"
 
+# The HIP runtime says nothing at its default log level before it gives up on a fatal error (one GPU test run of round 3 ended in
+# a bare abort() inside mpc_compress_batch, not reproducible, with an empty stderr): errors only, set before the runtime starts.
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
