@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -235,7 +236,12 @@ void parallel_copy(void *dst, const void *src, size_t bytes)
     const size_t off = (size_t)i * per;
     if (off >= bytes) break;
     const size_t n = std::min(per, bytes - off);
-    th.emplace_back([=]() { std::memcpy((char *)dst + off, (const char *)src + off, n); });
+    // (no exception may leave the library: a thread that cannot be started -- the host's thread limit -- copies here instead)
+    try {
+      th.emplace_back([=]() { std::memcpy((char *)dst + off, (const char *)src + off, n); });
+    } catch (const std::system_error &) {
+      std::memcpy((char *)dst + off, (const char *)src + off, n);
+    }
   }
   for (auto &t : th) t.join();
 }
@@ -259,7 +265,13 @@ bool parallel_pread(int fd, void *dst, size_t bytes, u64 file_off)
     }
   };
   std::vector<std::thread> th;
-  for (unsigned i = 1; i < nt; i++) th.emplace_back(work, i);
+  for (unsigned i = 1; i < nt; i++) {
+    try {
+      th.emplace_back(work, i);
+    } catch (const std::system_error &) {
+      work(i);          // (the host's thread limit: read this part here)
+    }
+  }
   work(0);
   for (auto &t : th) t.join();
   for (int v : ok) if (!v) return false;
